@@ -1,0 +1,44 @@
+// glp_ctx.h — the opaque context behind include/glprover.h (internal to libglprover.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include "../../include/glprover.h"
+#include "gl_field.cuh"
+#include "ntt_plan.h"
+
+struct glp_table { u64* lo; u64* hi; };
+struct glp_hash_state;
+
+struct glp_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;        // own_stream or an adopted one
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t pass_ev[2 * GLP_MAX_PASSES] = {};
+    int profiling = 0;
+    int last_npass = 0;
+    char err[512] = {0};
+    std::map<int, glp_table> tables;     // key = log_N*2 + inv
+    std::map<uint32_t, std::string> plan_override;
+    u64* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    size_t scratch_cap = 0;              // upper bound for NTT scratch; larger batches are chunked
+    u64* shift_lo = nullptr;             // cached shift^j tables of the last glp_lde_coset
+    u64* shift_hi = nullptr;
+    u64 shift_val = 0;
+    int shift_log_n = -1;
+    glp_hash_state* hash = nullptr;      // Poseidon constants etc. (hash.hip)
+};
+
+void glp_set_err(glp_ctx* c, const char* fmt, ...);
+void glp_hash_destroy(glp_ctx* c);
+
+#define GLP_HIPCHK(c, expr)                                                                    \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            glp_set_err((c), "%s:%d %s: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return GLP_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)

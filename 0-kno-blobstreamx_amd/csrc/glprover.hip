@@ -1,0 +1,381 @@
+// glprover.hip — C-ABI implementation (include/glprover.h): context, device memory,
+// twiddle-table cache, NTT/LDE/transpose entry points.  Host orchestration is C++17 because
+// the reference's host language (Rust) has no toolchain in this image;
+// a Rust host binds the same header.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/glprover.h"
+#include "glp_ctx.h"
+#include "ntt_exec.h"
+#include "ntt_launch.h"
+
+void glp_set_err(glp_ctx* c, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------
+// small utility kernels
+// ---------------------------------------------------------------------------------------
+// out[b][j] = j < n ? coeffs[b][j] * shift^j : 0   (shift^j = s_lo[j & 4095] * s_hi[j >> 12])
+__global__ void __launch_bounds__(256) glp_lde_prep_kernel(const u64* __restrict__ coeffs, u64* __restrict__ out,
+                                                           u32 log_n, u32 log_N, u32 batch, const u64* __restrict__ s_lo,
+                                                           const u64* __restrict__ s_hi) {
+    const u64 N = 1ull << log_N, n = 1ull << log_n;
+    const u64 total = (u64)batch << log_N;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u64 b = i >> log_N, j = i & (N - 1);
+        u64 v = 0;
+        if (j < n) {
+            v = coeffs[b * n + j];
+            u64 s = s_lo[j & 4095u];
+            if (s_hi) s = gl_mul(s, s_hi[j >> 12]);
+            v = gl_mul(v, s);
+        }
+        out[i] = v;
+    }
+}
+
+// [rows][cols] -> [cols][rows], 32x32 u64 tiles through LDS (row pad = 1 element)
+__global__ void __launch_bounds__(256) glp_transpose_kernel(const u64* __restrict__ in, u64* __restrict__ out, u64 rows,
+                                                            u64 cols, u64 tiles_c) {
+    __shared__ u64 t[32][33];
+    const u64 tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
+    const u32 tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;   // 32 x 8
+    for (u32 k = 0; k < 32; k += 8) {
+        const u64 r = tile_r * 32 + ty + k, c = tile_c * 32 + tx;
+        if (r < rows && c < cols) t[ty + k][tx] = in[r * cols + c];
+    }
+    __syncthreads();
+    for (u32 k = 0; k < 32; k += 8) {
+        const u64 c = tile_c * 32 + ty + k, r = tile_r * 32 + tx;
+        if (r < rows && c < cols) out[c * rows + r] = t[tx][ty + k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// twiddle tables
+// ---------------------------------------------------------------------------------------
+static int ensure_table(glp_ctx* c, int log_N, int inv) {
+    const int key = log_N * 2 + (inv ? 1 : 0);
+    if (c->tables.count(key)) return GLP_OK;
+    const size_t nlo = glp_table_lo_len(log_N), nhi = glp_table_hi_len(log_N);
+    std::vector<u64> lo(nlo), hi(nhi ? nhi : 1);
+    glp_fill_table(log_N, inv, lo.data(), hi.data());
+    glp_table t{nullptr, nullptr};
+    GLP_HIPCHK(c, hipMalloc((void**)&t.lo, nlo * 8));
+    GLP_HIPCHK(c, hipMemcpy(t.lo, lo.data(), nlo * 8, hipMemcpyHostToDevice));
+    if (nhi) {
+        GLP_HIPCHK(c, hipMalloc((void**)&t.hi, nhi * 8));
+        GLP_HIPCHK(c, hipMemcpy(t.hi, hi.data(), nhi * 8, hipMemcpyHostToDevice));
+    }
+    c->tables[key] = t;
+    return GLP_OK;
+}
+
+namespace {
+struct HipBackend {
+    glp_ctx* c;
+    int rc = GLP_OK;
+    int npass = 0;
+    const u64* table_lo(int log_N, int inv) {
+        if (ensure_table(c, log_N, inv) != GLP_OK) { rc = GLP_E_HIP; return nullptr; }
+        return c->tables[log_N * 2 + (inv ? 1 : 0)].lo;
+    }
+    const u64* table_hi(int log_N, int inv) {
+        if (ensure_table(c, log_N, inv) != GLP_OK) { rc = GLP_E_HIP; return nullptr; }
+        return c->tables[log_N * 2 + (inv ? 1 : 0)].hi;
+    }
+    void mark(int idx) {
+        if (c->profiling && idx < 2 * GLP_MAX_PASSES) hipEventRecord(c->pass_ev[idx], c->stream);
+    }
+    int launch_pass(const GlpPass& ps, int inv, unsigned long long grid, unsigned block, size_t lds, const GlpNttPassArgs& a) {
+        if (rc != GLP_OK) return rc;
+        if (lds > 160 * 1024 || block > 1024 || block < 64) { glp_set_err(c, "bad launch geometry"); return GLP_E_INVALID; }
+        mark(2 * npass);
+        hipError_t e = glp_launch_ntt_pass(ps.log_r, ps.mode, inv, (unsigned)grid, block, lds, c->stream, &a);
+        mark(2 * npass + 1);
+        npass++;
+        if (e != hipSuccess) { glp_set_err(c, "ntt pass launch: %s", hipGetErrorString(e)); return GLP_E_HIP; }
+        return GLP_OK;
+    }
+    int launch_small(const u64* src, u64* dst, u64 ss, u64 ds, u32 log_n, u32 batch, const u64* tw, u64 scale, u32 rev) {
+        if (rc != GLP_OK) return rc;
+        mark(0);
+        hipLaunchKernelGGL(glp_ntt_small_kernel<0>, dim3((batch + 255) / 256), dim3(256), 0, c->stream, src, dst, ss, ds, log_n,
+                           batch, tw, scale, rev);
+        mark(1);
+        npass = 1;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { glp_set_err(c, "small ntt launch: %s", hipGetErrorString(e)); return GLP_E_HIP; }
+        return GLP_OK;
+    }
+};
+}  // namespace
+
+static int ensure_scratch(glp_ctx* c, size_t bytes) {
+    if (c->scratch_bytes >= bytes) return GLP_OK;
+    if (c->scratch) { hipStreamSynchronize(c->stream); hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    hipError_t e = hipMalloc((void**)&c->scratch, bytes);
+    if (e != hipSuccess) { glp_set_err(c, "scratch alloc of %zu bytes: %s", bytes, hipGetErrorString(e)); return GLP_E_NOMEM; }
+    c->scratch_bytes = bytes;
+    return GLP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" const char* glp_version(void) { return "glprover 0.1 (gfx950)"; }
+
+extern "C" int glp_create(glp_ctx** out, int device_id) {
+    if (!out) return GLP_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GLP_E_NODEVICE;
+    if (device_id < 0 || device_id >= ndev) return GLP_E_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return GLP_E_NODEVICE;
+    glp_ctx* c = new glp_ctx();
+    c->device = device_id;
+    c->err[0] = 0;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GLP_E_HIP; }
+    c->stream = c->own_stream;
+    hipEventCreate(&c->t0);
+    hipEventCreate(&c->t1);
+    for (int i = 0; i < 2 * GLP_MAX_PASSES; i++) hipEventCreate(&c->pass_ev[i]);
+    const char* cap = getenv("GLP_SCRATCH_CAP_MB");
+    c->scratch_cap = (cap && atoll(cap) > 0) ? (size_t)atoll(cap) << 20 : (size_t)4 << 30;
+    *out = c;
+    return GLP_OK;
+}
+
+extern "C" void glp_destroy(glp_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->tables) { if (kv.second.lo) hipFree(kv.second.lo); if (kv.second.hi) hipFree(kv.second.hi); }
+    if (c->shift_lo) hipFree(c->shift_lo);
+    if (c->shift_hi) hipFree(c->shift_hi);
+    if (c->scratch) hipFree(c->scratch);
+    glp_hash_destroy(c);
+    hipEventDestroy(c->t0);
+    hipEventDestroy(c->t1);
+    for (int i = 0; i < 2 * GLP_MAX_PASSES; i++) hipEventDestroy(c->pass_ev[i]);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" const char* glp_last_error(const glp_ctx* c) { return c ? c->err : "null ctx"; }
+
+extern "C" int glp_alloc(glp_ctx* c, void** d_ptr, size_t bytes) {
+    if (!c || !d_ptr) return GLP_E_INVALID;
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) { glp_set_err(c, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return GLP_E_NOMEM; }
+    return GLP_OK;
+}
+extern "C" int glp_free(glp_ctx* c, void* d_ptr) {
+    if (!c) return GLP_E_INVALID;
+    if (!d_ptr) return GLP_OK;
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+    GLP_HIPCHK(c, hipFree(d_ptr));
+    return GLP_OK;
+}
+extern "C" int glp_h2d(glp_ctx* c, void* d, const void* h, size_t bytes) {
+    if (!c || (!d && bytes) || (!h && bytes)) return GLP_E_INVALID;
+    GLP_HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+extern "C" int glp_d2h(glp_ctx* c, void* h, const void* d, size_t bytes) {
+    if (!c || (!d && bytes) || (!h && bytes)) return GLP_E_INVALID;
+    GLP_HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+extern "C" int glp_sync(glp_ctx* c) {
+    if (!c) return GLP_E_INVALID;
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+extern "C" int glp_set_stream(glp_ctx* c, void* s) {
+    if (!c) return GLP_E_INVALID;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return GLP_OK;
+}
+extern "C" int glp_timer_start(glp_ctx* c) {
+    if (!c) return GLP_E_INVALID;
+    GLP_HIPCHK(c, hipEventRecord(c->t0, c->stream));
+    return GLP_OK;
+}
+extern "C" int glp_timer_stop(glp_ctx* c, float* ms) {
+    if (!c || !ms) return GLP_E_INVALID;
+    GLP_HIPCHK(c, hipEventRecord(c->t1, c->stream));
+    GLP_HIPCHK(c, hipEventSynchronize(c->t1));
+    GLP_HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    return GLP_OK;
+}
+
+extern "C" int glp_ntt_set_plan(glp_ctx* c, uint32_t log_n, const char* plan) {
+    if (!c || log_n > 32) return GLP_E_INVALID;
+    if (plan && *plan) {
+        GlpPlan pl;
+        if (log_n < GLP_MIN_LOG_R) return GLP_E_INVALID;
+        int lr[GLP_MAX_PASSES], lc[GLP_MAX_PASSES];
+        int np = glp_parse_plan(plan, lr, lc), sum = 0;
+        for (int i = 0; i < np; i++) sum += lr[i];
+        if (np == 0 || sum != (int)log_n || glp_make_plan((int)log_n, 0, 1, plan, &pl) != 0) {
+            glp_set_err(c, "plan '%s' does not fit log_n=%u", plan, log_n);
+            return GLP_E_INVALID;
+        }
+        c->plan_override[log_n] = plan;
+    } else {
+        c->plan_override.erase(log_n);
+    }
+    return GLP_OK;
+}
+
+static const char* plan_override_for(glp_ctx* c, uint32_t log_n) {
+    auto it = c->plan_override.find(log_n);
+    if (it != c->plan_override.end()) return it->second.c_str();
+    const char* env = getenv("GLP_NTT_PLAN");   // applies to every size it sums to
+    return env;
+}
+
+extern "C" int glp_ntt_describe_plan(glp_ctx* c, uint32_t log_n, uint32_t flags, char* buf, size_t len) {
+    if (!c || !buf || len == 0) return GLP_E_INVALID;
+    if (log_n < GLP_MIN_LOG_R) { snprintf(buf, len, "small(n=%u)", 1u << log_n); return GLP_OK; }
+    GlpPlan pl;
+    if (glp_make_plan((int)log_n, (flags & GLP_NTT_BITREV) ? 1 : 0, 1, plan_override_for(c, log_n), &pl) != 0) return GLP_E_UNSUPPORTED;
+    size_t off = 0;
+    static const char* mn[] = {"strip", "finalT", "finalRows"};
+    for (int i = 0; i < pl.npass && off < len; i++)
+        off += (size_t)snprintf(buf + off, len - off, "%s%s(R=2^%d,C=2^%d)", i ? "+" : "", mn[pl.p[i].mode], pl.p[i].log_r, pl.p[i].log_c);
+    return GLP_OK;
+}
+
+extern "C" int glp_set_profiling(glp_ctx* c, int on) {
+    if (!c) return GLP_E_INVALID;
+    c->profiling = on ? 1 : 0;
+    c->last_npass = 0;
+    return GLP_OK;
+}
+extern "C" int glp_last_pass_ms(glp_ctx* c, float* ms, int* n_out) {
+    if (!c || !ms || !n_out) return GLP_E_INVALID;
+    *n_out = 0;
+    if (!c->profiling) return GLP_E_STATE;
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->last_npass; i++) GLP_HIPCHK(c, hipEventElapsedTime(&ms[i], c->pass_ev[2 * i], c->pass_ev[2 * i + 1]));
+    *n_out = c->last_npass;
+    return GLP_OK;
+}
+
+int glp_ntt_impl(glp_ctx* c, const uint64_t* src, uint64_t* dst, uint32_t log_n, uint32_t batch, uint64_t ss, uint64_t ds,
+                 uint32_t flags) {
+    if (!c) return GLP_E_INVALID;
+    if (!src || !dst || log_n > 32 || (flags & ~(GLP_NTT_INVERSE | GLP_NTT_BITREV))) { glp_set_err(c, "glp_ntt: bad argument"); return GLP_E_INVALID; }
+    const u64 n = 1ull << log_n;
+    if (batch > 1 && (ss < n || ds < n)) { glp_set_err(c, "glp_ntt: poly stride < n"); return GLP_E_INVALID; }
+    if (src != dst) {
+        // partial overlap is not supported
+        const u64 span_s = (u64)(batch ? batch - 1 : 0) * ss + n, span_d = (u64)(batch ? batch - 1 : 0) * ds + n;
+        if (src < dst + span_d && dst < src + span_s) { glp_set_err(c, "glp_ntt: src/dst overlap"); return GLP_E_INVALID; }
+    } else if (ss != ds) { glp_set_err(c, "glp_ntt: in place needs equal strides"); return GLP_E_INVALID; }
+    if (batch == 0) return GLP_OK;
+    if (log_n == 0) {
+        if (src != dst) GLP_HIPCHK(c, hipMemcpy2DAsync(dst, ds * 8, src, ss * 8, 8, batch, hipMemcpyDeviceToDevice, c->stream));
+        return GLP_OK;
+    }
+    const int inv = (flags & GLP_NTT_INVERSE) ? 1 : 0, rev = (flags & GLP_NTT_BITREV) ? 1 : 0;
+    GlpPlan pl;
+    memset(&pl, 0, sizeof(pl));
+    if (log_n >= GLP_MIN_LOG_R) {
+        if (glp_make_plan((int)log_n, rev, src == dst, plan_override_for(c, log_n), &pl) != 0) {
+            glp_set_err(c, "glp_ntt: no plan for log_n=%u", log_n);
+            return GLP_E_UNSUPPORTED;
+        }
+    }
+    // bounded scratch: process the batch in chunks of `chunk` polynomials
+    u32 chunk = batch;
+    if (pl.needs_scratch) {
+        u64 per_poly = n * 8;
+        u64 maxp = c->scratch_cap / per_poly;
+        if (maxp == 0) maxp = 1;
+        if (chunk > maxp) chunk = (u32)maxp;
+        int rc = ensure_scratch(c, (size_t)chunk * per_poly);
+        if (rc != GLP_OK) return rc;
+    }
+    HipBackend be{c};
+    for (u32 b0 = 0; b0 < batch; b0 += chunk) {
+        const u32 nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+        GlpNttCall call{src + (u64)b0 * ss, dst + (u64)b0 * ds, c->scratch, ss, ds, nb, (int)log_n, inv, rev};
+        be.npass = 0;
+        int rc = glp_exec_ntt(be, &pl, call);
+        if (rc != GLP_OK) { if (rc > -10 && c->err[0] == 0) glp_set_err(c, "glp_ntt: exec rc=%d", rc); return rc < -6 ? GLP_E_INVALID : rc; }
+    }
+    c->last_npass = be.npass;
+    return GLP_OK;
+}
+
+extern "C" int glp_ntt_ex(glp_ctx* c, const uint64_t* src, uint64_t* dst, uint32_t log_n, uint32_t batch, uint64_t ss,
+                          uint64_t ds, uint32_t flags) {
+    return glp_ntt_impl(c, src, dst, log_n, batch, ss, ds, flags);
+}
+extern "C" int glp_ntt(glp_ctx* c, uint64_t* d_io, uint32_t log_n, uint32_t batch, int inverse) {
+    const u64 n = log_n <= 32 ? (1ull << log_n) : 0;
+    return glp_ntt_impl(c, d_io, d_io, log_n, batch, n, n, inverse ? GLP_NTT_INVERSE : 0u);
+}
+
+extern "C" int glp_lde_coset(glp_ctx* c, const uint64_t* coeffs, uint64_t* out, uint32_t log_n, uint32_t rate_bits,
+                             uint32_t batch, uint64_t shift, uint32_t flags) {
+    if (!c) return GLP_E_INVALID;
+    if (!coeffs || !out || log_n + rate_bits > 32 || shift == 0 || shift >= GL_P || (flags & ~GLP_NTT_BITREV)) {
+        glp_set_err(c, "glp_lde_coset: bad argument");
+        return GLP_E_INVALID;
+    }
+    if (batch == 0) return GLP_OK;
+    const u32 log_N = log_n + rate_bits;
+    const u64 n = 1ull << log_n;
+    // shift^j tables (two-level), cached for the last (shift, log_n)
+    if (c->shift_val != shift || c->shift_log_n != (int)log_n) {
+        const size_t nlo = n < 4096 ? n : 4096, nhi = n > 4096 ? (n >> 12) : 0;
+        std::vector<u64> lo(nlo), hi(nhi ? nhi : 1);
+        u64 t = 1;
+        for (size_t i = 0; i < nlo; i++) { lo[i] = t; t = gl_mul(t, shift); }
+        if (nhi) { u64 sh = gl_pow(shift, 4096); t = 1; for (size_t i = 0; i < nhi; i++) { hi[i] = t; t = gl_mul(t, sh); } }
+        GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->shift_lo) { hipFree(c->shift_lo); c->shift_lo = nullptr; }
+        if (c->shift_hi) { hipFree(c->shift_hi); c->shift_hi = nullptr; }
+        GLP_HIPCHK(c, hipMalloc((void**)&c->shift_lo, nlo * 8));
+        GLP_HIPCHK(c, hipMemcpy(c->shift_lo, lo.data(), nlo * 8, hipMemcpyHostToDevice));
+        if (nhi) {
+            GLP_HIPCHK(c, hipMalloc((void**)&c->shift_hi, nhi * 8));
+            GLP_HIPCHK(c, hipMemcpy(c->shift_hi, hi.data(), nhi * 8, hipMemcpyHostToDevice));
+        }
+        c->shift_val = shift;
+        c->shift_log_n = (int)log_n;
+    }
+    const u64 total = (u64)batch << log_N;
+    u64 blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(glp_lde_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, coeffs, out, log_n, log_N, batch,
+                       c->shift_lo, c->shift_hi);
+    GLP_HIPCHK(c, hipGetLastError());
+    const u64 N = 1ull << log_N;
+    return glp_ntt_impl(c, out, out, log_N, batch, N, N, flags & GLP_NTT_BITREV);
+}
+
+extern "C" int glp_transpose(glp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t rows, uint64_t cols) {
+    if (!c) return GLP_E_INVALID;
+    if (!in || !out || in == out) { glp_set_err(c, "glp_transpose: bad argument"); return GLP_E_INVALID; }
+    if (rows == 0 || cols == 0) return GLP_OK;
+    const u64 tr = (rows + 31) / 32, tc = (cols + 31) / 32;
+    if (tr * tc > 0x7fffffffull) { glp_set_err(c, "glp_transpose: too large"); return GLP_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(glp_transpose_kernel, dim3((unsigned)(tr * tc)), dim3(256), 0, c->stream, in, out, rows, cols, tc);
+    GLP_HIPCHK(c, hipGetLastError());
+    return GLP_OK;
+}

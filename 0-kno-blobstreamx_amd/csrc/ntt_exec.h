@@ -1,0 +1,80 @@
+// ntt_exec.h — turns a GlpPlan into kernel launches.  Templated on a Backend so that the
+// HIP host (glprover.hip) and the CPU emulation used by the tests (tests/emu) share the
+// exact pass sequencing, argument construction and twiddle-table selection.
+//
+// Backend concept:
+//   const u64* table_lo(int log_N, int inv);   // device-visible tables (glp_fill_table)
+//   const u64* table_hi(int log_N, int inv);   // nullptr when log_N <= 12
+//   int launch_pass(const GlpPass&, int inv, unsigned long long grid, unsigned block, size_t lds, const GlpNttPassArgs&);
+//   int launch_small(const u64* src, u64* dst, u64 ss, u64 ds, u32 log_n, u32 batch, const u64* tw, u64 scale, u32 rev);
+#pragma once
+#include "ntt_kernels.cuh"
+#include "ntt_plan.h"
+
+struct GlpNttCall {
+    const u64* src;
+    u64* dst;
+    u64* scratch;          // batch << log_n elements when the plan needs it
+    u64 src_poly_stride;   // elements
+    u64 dst_poly_stride;
+    u32 batch;
+    int log_n;
+    int inverse;
+    int rev;               // bit-reversed output order
+};
+
+template <class Backend>
+int glp_exec_ntt(Backend& be, const GlpPlan* pl, const GlpNttCall& c) {
+    const u64 n = 1ull << c.log_n;
+    const u64 scale = c.inverse ? gl_inv(n % GL_P) : 1ull;
+    if (c.batch == 0) return 0;
+    if (c.log_n < GLP_MIN_LOG_R) {
+        return be.launch_small(c.src, c.dst, c.src_poly_stride, c.dst_poly_stride, (u32)c.log_n, c.batch,
+                               be.table_lo(c.log_n, c.inverse), scale, (u32)c.rev);
+    }
+    int rem = c.log_n;
+    for (int i = 0; i < pl->npass; i++) {
+        const GlpPass& ps = pl->p[i];
+        GlpNttPassArgs a;
+        memset(&a, 0, sizeof(a));
+        const u64* in; u64 in_stride;
+        u64* out; u64 out_stride;
+        switch (ps.in_buf) {
+            case GLP_BUF_SRC: in = c.src; in_stride = c.src_poly_stride; break;
+            case GLP_BUF_DST: in = c.dst; in_stride = c.dst_poly_stride; break;
+            default: in = c.scratch; in_stride = n; break;
+        }
+        switch (ps.out_buf) {
+            case GLP_BUF_DST: out = c.dst; out_stride = c.dst_poly_stride; break;
+            case GLP_BUF_SCRATCH: out = c.scratch; out_stride = n; break;
+            default: return -2;
+        }
+        if ((ps.in_buf == GLP_BUF_SCRATCH || ps.out_buf == GLP_BUF_SCRATCH) && !c.scratch) return -3;
+        a.src = in; a.dst = out;
+        a.src_poly_stride = in_stride; a.dst_poly_stride = out_stride;
+        a.tw_tile = be.table_lo(ps.log_r, c.inverse);
+        const int log_N = rem;            // size of the sub-problem this pass splits
+        rem -= ps.log_r;
+        if (ps.mode == GLP_STRIP) {
+            a.tw_lo = be.table_lo(log_N, c.inverse);
+            a.tw_hi = be.table_hi(log_N, c.inverse);
+        }
+        const int last = (i == pl->npass - 1);
+        a.scale = last ? scale : 1ull;
+        a.log_n = (u32)c.log_n;
+        a.log_m = (u32)ps.log_m;
+        a.log_c = (u32)ps.log_c;
+        a.batch = c.batch;
+        a.rev = (u32)c.rev;
+        a.nprev = 0;
+        if (ps.mode == GLP_FINAL_T) {
+            a.nprev = (u32)i;
+            for (int j = 0; j < i && j < 3; j++) a.log_rprev[j] = (u32)pl->p[j].log_r;
+        }
+        unsigned long long grid = glp_pass_grid(&ps, c.log_n, c.batch);
+        if (grid == 0 || grid > 0x7fffffffull) return -4;
+        int rc = be.launch_pass(ps, c.inverse, grid, glp_pass_threads(&ps), glp_pass_lds_bytes(&ps), a);
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,321 @@
+// ntt_kernels.cuh — Goldilocks radix-2^k NTT pass kernels for gfx950 (SURVEY.md §8a row a2;
+// upstream names recalled as plonky2_field::fft::{fft, ifft, coset_fft, lde} — reference
+// file:line: NONE, /root/reference holds no source).
+//
+// One transform of size n = R_1 * R_2 * ... * R_P is P launches ("passes") of ONE kernel
+// template.  Pass i computes, for every other index, a size-R_i DFT along the axis whose
+// stride is m_i = n / (R_1...R_i), then multiplies by the inter-pass twiddle
+// w_{R_i*m_i}^{j' * k_i} (decimation in frequency: big strides first, twiddle after).
+//
+// A workgroup owns a tile of R rows x C columns (C = 2^log_c adjacent "other" indices), 16
+// elements per thread, NT = R*C/16 threads:
+//   STRIP      rows are m apart in memory, the C columns are contiguous (C*8-byte segments);
+//              results go back to the same tile positions (or the same positions of dst).
+//   FINAL_T    last pass of a natural-order transform: the C "columns" are C whole
+//              contiguous rows of src; X[k] is written to its natural position, which
+//              is a C-wide contiguous segment per k (the digit-reversal transpose is paid
+//              here, in C*8-byte segments, and nowhere else).
+//   FINAL_ROWS last/only pass when outputs stay in their row (single-pass transforms,
+//              or bit-reversed output): results are restaged through LDS and written as
+//              whole contiguous rows.
+// Inside the tile the size-R DFT is ceil(log2 R / 4) register steps of radix <= 16, with an
+// LDS exchange ([R][C+1] u64, +1 pad = conflict-free for both access patterns) between
+// steps.  Radix-16 butterflies use only shift twiddles (w_16 = 2^156); one table twiddle
+// per element per step boundary.
+//
+// This file is plain HIP C++ with no AMD builtins so that tests/emu can run the very same
+// kernel bodies on the CPU under ASan (test infrastructure; the product never does).
+#pragma once
+#include "gl_field.cuh"
+#include "ntt_plan.h"
+
+template <int V> struct glp_ic { static constexpr int value = V; };
+template <int I, int N, class F>
+GL_HD void glp_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(glp_ic<I>{});
+        glp_static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int glp_bitrev_c(int v, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+// exponent e with w_m^i = 2^e (m = 2^k <= 64): w_64 = 2^39 under the generator-7 roots.
+constexpr int glp_tw_exp(int m, int i, bool inv) {
+    int e = (39 * (64 / m) * i) % 192;
+    return inv ? (192 - e) % 192 : e;
+}
+
+// In-register DIF DFT of size 2^Q on x[OFF .. OFF+2^Q); X[k] lands in x[OFF + bitrev_Q(k)].
+template <int Q, bool INV, int OFF>
+GL_HD void glp_dft_inreg(u64 (&x)[16]) {
+    glp_static_for<0, Q>([&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+        constexpr int half = 1 << (Q - 1 - s);
+        constexpr int m = 2 * half;
+        glp_static_for<0, (1 << Q) / 2>([&](auto t_) {
+            constexpr int t = decltype(t_)::value;
+            constexpr int blk = t / half, i = t % half;
+            constexpr int i0 = OFF + blk * m + i, i1 = i0 + half;
+            constexpr int e = glp_tw_exp(m, i, INV);
+            u64 u = x[i0], v = x[i1];
+            x[i0] = gl_add(u, v);
+            if constexpr (e >= 96) x[i1] = gl_mul_pow2<e - 96>(gl_sub(v, u));
+            else x[i1] = gl_mul_pow2<e>(gl_sub(u, v));
+        });
+    });
+}
+
+
+struct GlpNttPassArgs {
+    const u64* src;
+    u64* dst;
+    u64 src_poly_stride;   // elements between consecutive polynomials in src
+    u64 dst_poly_stride;
+    const u64* tw_tile;    // w_R^e, e < R          (inverse powers when INV)
+    const u64* tw_lo;      // w_N^e, e < min(N,4096), N = R*m   (STRIP only, m > 1)
+    const u64* tw_hi;      // w_N^(4096 e), e < N/4096          (only when N > 4096)
+    u64 scale;             // multiply every output by this (1 = none); inverse: n^-1
+    u32 log_n;             // transform size
+    u32 log_m;             // STRIP: log2 of the axis stride m
+    u32 log_c;             // log2 of columns per tile
+    u32 batch;             // number of polynomials
+    u32 rev;               // bit-reversed output order (STRIP: row placement; FINAL_ROWS: index)
+    u32 nprev;             // FINAL_T: number of earlier passes, and their log2 radices
+    u32 log_rprev[3];
+};
+
+template <int LOG_R>
+struct GlpSteps {
+    static constexpr int S = (LOG_R + 3) / 4;                       // register steps
+    static constexpr int q(int t) { return t == 0 ? LOG_R - 4 * (S - 1) : 4; }  // small radix first
+    static constexpr int log_sigma(int t) { return 4 * (S - 1 - t); }           // stride of digit t
+    static constexpr int low_bits(int t) { return t == 0 ? 0 : q(0) + 4 * (t - 1); }
+};
+
+// natural index k of the value sitting at tile row `pos` after all steps (digit reversal)
+template <int LOG_R>
+GL_HD u32 glp_digit_reverse(u32 pos) {
+    using ST = GlpSteps<LOG_R>;
+    u32 k = 0;
+    glp_static_for<0, ST::S>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        u32 digit = (pos >> ST::log_sigma(t)) & ((1u << ST::q(t)) - 1u);
+        k |= digit << ST::low_bits(t);
+    });
+    return k;
+}
+
+GL_HD u32 glp_bitrev32(u32 v, u32 bits) {
+    if (bits == 0) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v) >> (32 - bits);
+#else
+    u32 r = 0;
+    for (u32 i = 0; i < bits; i++) r |= ((v >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+#if defined(GLP_EMU)
+#define GLP_DYN_LDS(name) u64* name = reinterpret_cast<u64*>(glp_emu_dyn_lds())
+#else
+#define GLP_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) u64 name[]
+#endif
+
+template <int LOG_R, int MODE, bool INV>
+__global__ void __launch_bounds__(1024) glp_ntt_pass_kernel(GlpNttPassArgs a) {
+    using ST = GlpSteps<LOG_R>;
+    constexpr u32 R = 1u << LOG_R;
+    GLP_DYN_LDS(lds);
+
+    const u32 log_c = a.log_c;
+    const u32 C = 1u << log_c;
+    const u32 NT = (R << log_c) >> 4;        // == blockDim.x (checked on the host)
+    const u32 tid = threadIdx.x;
+    const u32 ldA = C + 1;                   // layout A: [row][C+1]
+    const u64 tile = blockIdx.x;
+
+    // ---- tile geometry -------------------------------------------------------------
+    // STRIP: tile -> (poly, hi, lo0); element (row, col) at  hi*R*m + row*m + lo0 + col
+    u64 sbase = 0, dbase = 0;
+    u32 lo0 = 0;
+    // FINAL_*: tile -> first of C global rows
+    u64 row_first = 0;
+    const u32 log_rows = a.log_n - LOG_R;    // rows per polynomial (FINAL modes)
+    if constexpr (MODE == GLP_STRIP) {
+        const u32 log_tpp = a.log_n - LOG_R - log_c;              // tiles per polynomial
+        const u64 poly = tile >> log_tpp;
+        const u32 t = (u32)(tile & ((1ull << log_tpp) - 1));
+        const u32 log_mc = a.log_m - log_c;
+        const u32 hi = t >> log_mc;
+        lo0 = (t & ((1u << log_mc) - 1u)) << log_c;
+        const u64 off = ((u64)hi << (LOG_R + a.log_m)) + lo0;
+        sbase = poly * a.src_poly_stride + off;
+        dbase = poly * a.dst_poly_stride + off;
+    } else {
+        row_first = tile << log_c;
+    }
+    const u64 total_rows = (u64)a.batch << log_rows;
+
+    u64 x[16];
+
+    glp_static_for<0, ST::S>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        constexpr int q = ST::q(t);
+        constexpr u32 r = 1u << q;
+        constexpr int lsg = ST::log_sigma(t);
+        constexpr u32 G = 16u / r;           // units per thread in this step
+        constexpr bool first = (t == 0), last = (t == ST::S - 1);
+
+        // ---- decode + load ---------------------------------------------------------
+        u32 colv[G], row0v[G], olov[G];
+        glp_static_for<0, (int)G>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            const u32 u = g * NT + tid;
+            u32 col, o;
+            if (first && MODE != GLP_STRIP) {   // lanes along the contiguous NTT axis
+                o = u & ((R >> q) - 1u);
+                col = u >> (LOG_R - q);
+            } else {                            // lanes along the C contiguous columns
+                col = u & (C - 1u);
+                o = u >> log_c;
+            }
+            const u32 o_lo = o & ((1u << lsg) - 1u);
+            const u32 o_hi = o >> lsg;
+            const u32 row0 = (o_hi << (q + lsg)) | o_lo;
+            colv[g] = col; row0v[g] = row0; olov[g] = o_lo;
+            if constexpr (first) {
+                if constexpr (MODE == GLP_STRIP) {
+                    const u64 p = sbase + col;
+                    glp_static_for<0, (int)r>([&](auto d_) {
+                        constexpr int d = decltype(d_)::value;
+                        x[g * r + d] = a.src[p + ((u64)(row0 + ((u32)d << lsg)) << a.log_m)];
+                    });
+                } else {
+                    u64 grow = row_first + col;      // global row handled by this column
+                    bool active = grow < total_rows;
+                    u64 poly = grow >> log_rows;
+                    u32 rr = (u32)(grow & ((1ull << log_rows) - 1));
+                    if constexpr (MODE == GLP_FINAL_T) {
+                        // rr is kappa = k_1 + R_1 k_2 + ...; source row = k_1*(Q/R_1) + k_2*(Q/R_1R_2) ...
+                        u32 rem = rr, sh = log_rows, rho = 0;
+                        for (u32 i = 0; i < a.nprev; i++) {
+                            u32 lr = a.log_rprev[i];
+                            sh -= lr;
+                            rho |= (rem & ((1u << lr) - 1u)) << sh;
+                            rem >>= lr;
+                        }
+                        rr = rho;
+                    }
+                    const u64 p = poly * a.src_poly_stride + ((u64)rr << LOG_R) + row0;
+                    glp_static_for<0, (int)r>([&](auto d_) {
+                        constexpr int d = decltype(d_)::value;
+                        x[g * r + d] = active ? a.src[p + ((u32)d << lsg)] : 0ull;
+                    });
+                }
+            } else {
+                const u32 base = row0 * ldA + col;
+                glp_static_for<0, (int)r>([&](auto d_) {
+                    constexpr int d = decltype(d_)::value;
+                    x[g * r + d] = lds[base + ((u32)d << lsg) * ldA];
+                });
+            }
+        });
+
+        if constexpr (last && MODE == GLP_FINAL_ROWS && !first) __syncthreads();  // A fully read before B is written
+
+        // ---- butterflies -----------------------------------------------------------
+        glp_static_for<0, (int)G>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            glp_dft_inreg<q, INV, g * (int)r>(x);
+        });
+
+        // ---- twiddle + store ---------------------------------------------------------
+        glp_static_for<0, (int)G>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            const u32 col = colv[g], row0 = row0v[g];
+            if constexpr (!last) {
+                // X[k_t = d] *= w_{r*sigma}^{o_lo * d}  ==  tw_tile[(o_lo*d) << low_bits(t)]
+                const u32 o_lo = olov[g];
+                const u32 base = row0 * ldA + col;
+                glp_static_for<0, (int)r>([&](auto d_) {
+                    constexpr int d = decltype(d_)::value;
+                    u64 v = x[g * r + glp_bitrev_c(d, q)];
+                    if constexpr (d != 0) v = gl_mul(v, a.tw_tile[(o_lo * (u32)d) << ST::low_bits(t)]);
+                    lds[base + ((u32)d << lsg) * ldA] = v;
+                });
+            } else {
+                glp_static_for<0, (int)r>([&](auto d_) {
+                    constexpr int d = decltype(d_)::value;
+                    u64 v = x[g * r + glp_bitrev_c(d, q)];
+                    const u32 pos = row0 + (u32)d;                  // sigma == 1 in the last step
+                    const u32 k = glp_digit_reverse<LOG_R>(pos);    // natural output index in [0,R)
+                    if constexpr (MODE == GLP_STRIP) {
+                        const u32 log_N = LOG_R + a.log_m;
+                        const u64 e = (u64)(lo0 + col) * k;         // < N <= 2^32
+                        if (log_N <= 12) {
+                            v = gl_mul(v, a.tw_lo[e]);
+                        } else {
+                            u64 w = gl_mul(a.tw_lo[e & 4095u], a.tw_hi[e >> 12]);
+                            v = gl_mul(v, w);
+                        }
+                        if (a.scale != 1) v = gl_mul(v, a.scale);
+                        const u32 orow = a.rev ? glp_bitrev32(k, LOG_R) : k;
+                        a.dst[dbase + ((u64)orow << a.log_m) + col] = v;
+                    } else if constexpr (MODE == GLP_FINAL_T) {
+                        if (a.scale != 1) v = gl_mul(v, a.scale);
+                        const u64 grow = row_first + col;           // = poly*Q + kappa
+                        if (grow < total_rows) {
+                            const u64 poly = grow >> log_rows;
+                            const u64 kappa = grow & ((1ull << log_rows) - 1);
+                            a.dst[poly * a.dst_poly_stride + ((u64)k << log_rows) + kappa] = v;
+                        }
+                    } else {
+                        if (a.scale != 1) v = gl_mul(v, a.scale);
+                        const u32 kout = a.rev ? glp_bitrev32(k, LOG_R) : k;
+                        lds[col * (R + 1u) + kout] = v;             // layout B: [col][R+1]
+                    }
+                });
+            }
+        });
+        if constexpr (!last || MODE == GLP_FINAL_ROWS) __syncthreads();
+    });
+
+    if constexpr (MODE == GLP_FINAL_ROWS) {
+        // coalesced write of C whole rows from layout B
+        #pragma unroll 4
+        for (u32 i = tid; i < (R << log_c); i += NT) {
+            const u32 col = i >> LOG_R, kk = i & (R - 1u);
+            const u64 grow = row_first + col;
+            if (grow < total_rows) {
+                const u64 poly = grow >> log_rows;
+                const u64 rr = grow & ((1ull << log_rows) - 1);
+                a.dst[poly * a.dst_poly_stride + (rr << LOG_R) + kk] = lds[col * (R + 1u) + kk];
+            }
+        }
+    }
+}
+
+// Transforms smaller than one tile (n < 64): one work-item per polynomial, O(n^2) with the
+// w_n^e table.  Sizes this small only occur at the tail of FRI and in tests.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_ntt_small_kernel(const u64* src, u64* dst, u64 src_poly_stride,
+                                                            u64 dst_poly_stride, u32 log_n, u32 batch,
+                                                            const u64* tw, u64 scale, u32 rev) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const u32 n = 1u << log_n;
+    u64 in[32];
+    for (u32 j = 0; j < n; j++) in[j] = src[(u64)b * src_poly_stride + j];
+    for (u32 k = 0; k < n; k++) {
+        u64 acc = 0;
+        for (u32 j = 0; j < n; j++) acc = gl_add(acc, gl_mul(in[j], tw[(j * k) & (n - 1u)]));
+        if (scale != 1) acc = gl_mul(acc, scale);
+        const u32 ko = rev ? glp_bitrev32(k, log_n) : k;
+        dst[(u64)b * dst_poly_stride + ko] = acc;
+    }
+}

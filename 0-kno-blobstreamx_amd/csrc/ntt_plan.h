@@ -1,0 +1,160 @@
+// ntt_plan.h — host-side planning for the Goldilocks NTT: how a size-2^log_n transform is
+// cut into passes of glp_ntt_pass_kernel, which twiddle tables each pass needs, and the
+// buffer each pass reads and writes.  Pure C++ (no HIP runtime) so that tests/emu can drive
+// the same plans on the CPU.
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "gl_field.cuh"
+
+#define GLP_MAX_PASSES 4
+#define GLP_MIN_LOG_R 6     // smallest tile transform served by the pass kernel
+#define GLP_MAX_LOG_R 12
+#define GLP_TW_SPLIT 12     // two-level twiddle tables: w^e = lo[e & 4095] * hi[e >> 12]
+
+enum { GLP_STRIP = 0, GLP_FINAL_T = 1, GLP_FINAL_ROWS = 2 };   // pass kernel modes (ntt_kernels.cuh)
+enum { GLP_BUF_SRC = 0, GLP_BUF_DST = 1, GLP_BUF_SCRATCH = 2 };
+
+struct GlpPass {
+    int log_r;     // tile transform size
+    int mode;      // GLP_STRIP / GLP_FINAL_T / GLP_FINAL_ROWS
+    int log_c;     // columns per tile
+    int log_m;     // STRIP: axis stride (log2); FINAL: 0
+    int in_buf;    // GLP_BUF_*
+    int out_buf;
+};
+
+struct GlpPlan {
+    int log_n;
+    int rev;       // bit-reversed output
+    int npass;
+    GlpPass p[GLP_MAX_PASSES];
+    int needs_scratch;
+};
+
+// default columns-per-tile: tiles of 2^12 elements (32 KiB) up to R = 2^8 ... see DESIGN.md
+static inline int glp_default_log_c(int log_r) {
+    int tile_log = log_r <= 8 ? 12 : (log_r <= 10 ? 13 : 14);
+    return tile_log - log_r;
+}
+
+// Parse "r:c,r:c,..." (log2 radix : log2 columns per pass); returns number of passes or 0.
+static inline int glp_parse_plan(const char* s, int* lr, int* lc) {
+    int n = 0;
+    while (s && *s && n < GLP_MAX_PASSES) {
+        int r = 0, c = -1, used = 0;
+        if (sscanf(s, "%d:%d%n", &r, &c, &used) < 2) {
+            if (sscanf(s, "%d%n", &r, &used) < 1) return 0;
+            c = -1;
+        }
+        lr[n] = r; lc[n] = c; n++;
+        s += used;
+        if (*s == ',') s++;
+    }
+    return n;
+}
+
+// Build the plan.  `ovr` optionally forces the radices ("12:2,12:2").  Returns 0 on success.
+// in_place: src == dst.
+static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ovr, GlpPlan* pl) {
+    memset(pl, 0, sizeof(*pl));
+    pl->log_n = log_n;
+    pl->rev = rev;
+    if (log_n < GLP_MIN_LOG_R || log_n > 32) return -1;
+    int lr[GLP_MAX_PASSES], lc[GLP_MAX_PASSES], np = 0;
+    if (ovr && *ovr) {
+        np = glp_parse_plan(ovr, lr, lc);
+        int sum = 0;
+        for (int i = 0; i < np; i++) sum += lr[i];
+        if (np == 0 || sum != log_n) np = 0;   // ignore an override that does not fit this size
+    }
+    if (np == 0) {
+        if (log_n <= GLP_MAX_LOG_R) { np = 1; lr[0] = log_n; }
+        else {
+            np = (log_n + GLP_MAX_LOG_R - 1) / GLP_MAX_LOG_R;
+            if (log_n > 20 && np < 3) np = 3;  // v0 heuristic: wide strips (C=16) over 2 narrow passes
+            int base = log_n / np, extra = log_n % np;
+            for (int i = 0; i < np; i++) lr[i] = base + (i < extra ? 1 : 0);
+        }
+        for (int i = 0; i < np; i++) lc[i] = -1;
+    }
+    if (np > GLP_MAX_PASSES) return -1;
+    pl->npass = np;
+    int rem = log_n;  // log2 of the remaining sub-problem size
+    for (int i = 0; i < np; i++) {
+        GlpPass* ps = &pl->p[i];
+        if (lr[i] < GLP_MIN_LOG_R || lr[i] > GLP_MAX_LOG_R) return -1;
+        ps->log_r = lr[i];
+        rem -= lr[i];
+        int last = (i == np - 1);
+        ps->mode = last ? ((rev || np == 1) ? GLP_FINAL_ROWS : GLP_FINAL_T) : GLP_STRIP;
+        ps->log_m = last ? 0 : rem;
+        int c = lc[i] >= 0 ? lc[i] : glp_default_log_c(lr[i]);
+        if (c + lr[i] < 10) c = 10 - lr[i];                 // at least one wavefront of threads
+        if (c + lr[i] > 14) c = 14 - lr[i];                 // at most 1024 threads
+        if (!last && c > rem) c = rem;                      // strip no wider than the axis stride
+        if (last && ps->mode == GLP_FINAL_T && c > log_n - lr[i]) c = log_n - lr[i];
+        if (c + lr[i] < 10 || c < 0) return -1;
+        // LDS footprint must fit 160 KiB: max(R*(C+1), C*(R+1)) * 8
+        while (c > 0) {
+            unsigned long long R = 1ull << lr[i], C = 1ull << c;
+            unsigned long long el = R * C + (R > C ? R : C);
+            if (el * 8 <= 160 * 1024) break;
+            c--;
+        }
+        if (c + lr[i] < 10) return -1;
+        ps->log_c = c;
+    }
+    // buffer routing.  STRIP passes may run in place; FINAL_T may not.
+    if (np == 1 || rev) {
+        for (int i = 0; i < np; i++) {
+            pl->p[i].in_buf = (i == 0) ? GLP_BUF_SRC : GLP_BUF_DST;
+            pl->p[i].out_buf = GLP_BUF_DST;
+        }
+        pl->needs_scratch = 0;
+    } else {
+        pl->needs_scratch = 1;
+        for (int i = 0; i < np; i++) {
+            int last = (i == np - 1);
+            if (last) { pl->p[i].in_buf = GLP_BUF_SCRATCH; pl->p[i].out_buf = GLP_BUF_DST; }
+            else if (i == np - 2) { pl->p[i].in_buf = (i == 0) ? GLP_BUF_SRC : (in_place ? GLP_BUF_DST : GLP_BUF_SCRATCH); pl->p[i].out_buf = GLP_BUF_SCRATCH; }
+            else {
+                // earlier strips: in place on dst when the caller's buffer is in place,
+                // otherwise move to scratch at the first pass and stay there
+                if (in_place) { pl->p[i].in_buf = GLP_BUF_DST; pl->p[i].out_buf = GLP_BUF_DST; }
+                else { pl->p[i].in_buf = (i == 0) ? GLP_BUF_SRC : GLP_BUF_SCRATCH; pl->p[i].out_buf = GLP_BUF_SCRATCH; }
+            }
+        }
+    }
+    return 0;
+}
+
+static inline size_t glp_pass_lds_bytes(const GlpPass* ps) {
+    unsigned long long R = 1ull << ps->log_r, C = 1ull << ps->log_c;
+    unsigned long long a = R * (C + 1), b = (ps->mode == GLP_FINAL_ROWS) ? C * (R + 1) : 0;
+    return (size_t)((a > b ? a : b) * 8);
+}
+static inline unsigned glp_pass_threads(const GlpPass* ps) { return 1u << (ps->log_r + ps->log_c - 4); }
+static inline unsigned long long glp_pass_grid(const GlpPass* ps, int log_n, unsigned long long batch) {
+    if (ps->mode == GLP_STRIP) return batch << (log_n - ps->log_r - ps->log_c);
+    unsigned long long rows = batch << (log_n - ps->log_r);
+    return (rows + (1ull << ps->log_c) - 1) >> ps->log_c;
+}
+
+// Twiddle table for w_N (N = 2^log_N): lo[e] = w^e for e < min(N, 4096); hi[e] = w^(4096 e)
+// for e < N/4096 (when N > 4096).  `inv` uses w^-1.
+static inline size_t glp_table_lo_len(int log_N) { return log_N <= GLP_TW_SPLIT ? (1ull << log_N) : (1ull << GLP_TW_SPLIT); }
+static inline size_t glp_table_hi_len(int log_N) { return log_N <= GLP_TW_SPLIT ? 0 : (1ull << (log_N - GLP_TW_SPLIT)); }
+static inline void glp_fill_table(int log_N, int inv, u64* lo, u64* hi) {
+    u64 w = gl_root_of_unity((unsigned)log_N);
+    if (inv) w = gl_inv(w);
+    size_t nlo = glp_table_lo_len(log_N), nhi = glp_table_hi_len(log_N);
+    u64 t = 1;
+    for (size_t i = 0; i < nlo; i++) { lo[i] = t; t = gl_mul(t, w); }
+    if (nhi) {
+        u64 wh = gl_pow(w, 1ull << GLP_TW_SPLIT);
+        t = 1;
+        for (size_t i = 0; i < nhi; i++) { hi[i] = t; t = gl_mul(t, wh); }
+    }
+}

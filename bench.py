@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — Goldilocks NTT GB/s on MI355X (BASELINE.json metric, second half).
+
+A "step" is one forward NTT over the whole batch, in place, natural order in and out, with
+the inputs already resident in HBM.  Default workload: n = 2^20, batch = 128 — the wires
+commitment shape of BASELINE.json configs[1] ("~2^20 gates", ~128 wire polynomials).
+Algorithmic bytes per step = 16 * n * batch (every element read once and
+written once).  value = algorithmic bytes of all ranks / max-over-ranks time.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): the batch dimension is
+sharded, every rank transforms its own `batch` polynomials, no data-path collective
+ — weak scaling.  torch is used for rendezvous/barrier only.
+
+Extra objects on the JSON line: "roofline" (HIP-event time of the pass kernels of one
+transform, measured live; HBM peak 8 TB/s), "cpu_baseline" (the CPU oracle timed on a
+bounded sample on this box's cores; rank 0, N=1 only) and "sizes" (GB/s at 2^20/2^22/2^24).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def splitmix_fill(n_elems, seed):
+    """element i = splitmix64(seed + i) mod p (SURVEY.md §8d inputs), vectorised"""
+    p = np.uint64(2**64 - 2**32 + 1)
+    with np.errstate(over="ignore"):
+        z = np.arange(n_elems, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z % p
+
+
+def time_ntt(pr, d, log_n, batch, steps, warmup):
+    for _ in range(warmup):
+        pr.ntt_(d, log_n, batch)
+    pr.sync()
+    pr.timer_start()
+    for _ in range(steps):
+        pr.ntt_(d, log_n, batch)
+    ms = pr.timer_stop()
+    return ms / steps
+
+
+def cpu_baseline(log_n, seconds_target=15.0):
+    """the CPU oracle (kind "port": the in-repo restatement; the Rust plonky2 prover cannot be
+    built here) on a bounded sample: `polys` transforms of size 2^log_n, OpenMP over the batch."""
+    orc = graft.load_oracle()
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    orc.orc_ntt.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint64, ctypes.c_int]
+    orc.orc_num_threads.restype = ctypes.c_int
+    cores = orc.orc_num_threads()
+    n = 1 << log_n
+    probe = splitmix_fill(n * cores, 1).reshape(cores, n)
+    t = time.perf_counter()
+    orc.orc_ntt(probe.ctypes.data_as(u64p), log_n, cores, 0)
+    dt = time.perf_counter() - t
+    rounds = max(1, min(64, int(seconds_target / max(dt, 1e-3))))
+    polys = cores * rounds
+    x = splitmix_fill(n * polys, 2).reshape(polys, n)
+    t = time.perf_counter()
+    orc.orc_ntt(x.ctypes.data_as(u64p), log_n, polys, 0)
+    dt = time.perf_counter() - t
+    return {"value": round(16.0 * n * polys / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"{polys} forward NTTs of 2^{log_n} (16*n bytes each), OpenMP over the batch, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the 2^20/2^22/2^24 sweep")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = graft.load_package()
+    pr = pkg.Prover(local_rank)
+    log_n, batch = args.log_n, args.batch
+    n = 1 << log_n
+
+    host = splitmix_fill(n * batch, 0x9E3779B97F4A7C15 + rank).reshape(batch, n)
+    d = pr.to_device(host)
+    del host
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        pr.sync()
+
+    for _ in range(args.warmup):
+        pr.ntt_(d, log_n, batch)
+    barrier()
+    t0 = time.perf_counter()
+    pr.timer_start()
+    for _ in range(args.steps):
+        pr.ntt_(d, log_n, batch)
+    ev_ms = pr.timer_stop()
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    ms_per_step = wall * 1e3 / args.steps
+    alg_bytes = 16.0 * n * batch
+    value = alg_bytes * world / (ms_per_step * 1e-3) / 1e9
+
+    out = None
+    if rank == 0:
+        # per-pass kernel times of ONE transform, HIP events on the ctx stream
+        pr.set_profiling(True)
+        acc = None
+        reps = max(3, min(args.steps, 10))
+        for _ in range(reps):
+            pr.ntt_(d, log_n, batch)
+            ms = pr.last_pass_ms()
+            acc = ms if acc is None else [a + b for a, b in zip(acc, ms)]
+        pr.set_profiling(False)
+        pass_ms = [a / reps for a in acc]
+        kern_ms = sum(pass_ms)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Goldilocks NTT GB/s @ 2^20-2^24", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"forward NTT, n=2^{log_n}, batch={batch} per GPU, in place, natural order "
+                                   f"(BASELINE configs[1] wires shape)", "log_n": log_n, "batch_per_gpu": batch,
+                       "plan": pr.describe_plan(log_n), "algorithmic_bytes_per_step": alg_bytes,
+                       "event_ms_per_step": round(ev_ms / args.steps, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "glp_ntt_pass_kernel (all passes of one transform)",
+                         "pass_ms": [round(m, 4) for m in pass_ms],
+                         "pass_gbps": [round(alg_bytes / (m * 1e-3) / 1e9, 1) for m in pass_ms]},
+        }
+    d.free()
+
+    if rank == 0 and not args.no_sizes:
+        sizes = {}
+        for ln, b in ((20, 1), (22, 1), (24, 1), (22, 32), (24, 8)):
+            x = splitmix_fill((1 << ln) * b, 5).reshape(b, 1 << ln)
+            dd = pr.to_device(x)
+            ms = time_ntt(pr, dd, ln, b, steps=10, warmup=3)
+            dd.free()
+            sizes[f"2^{ln}xb{b}"] = {"ms": round(ms, 4), "gbps": round(16.0 * (1 << ln) * b / (ms * 1e-3) / 1e9, 1),
+                                     "plan": pr.describe_plan(ln)}
+        out["sizes"] = sizes
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(log_n)
+    pr.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

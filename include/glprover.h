@@ -1,0 +1,85 @@
+/*
+ * glprover.h — C ABI of the MI355X-native Goldilocks prover kernels (libglprover.so).
+ *
+ * This is the drop-in boundary SURVEY.md §8(b) defines.  The north_star asks for "Rust
+ * calling the kernels through a thin extern-"C" FFI"; the reference mount
+ * (/root/reference: `.gitignore:1`, `changelog.md:1-2`, nothing else) contains no FFI, no
+ * Rust and no interface file, so for every entry point below the "reference interface it
+ * replaces" is:  file:line NONE — absent from mount.  The upstream function each one
+ * stands in for is given by NAME ONLY, recalled and unverified, so a
+ * maintainer knows where the Rust binding of INTEGRATION.md would be called from.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative GLP_E* code
+ *     and never aborts; glp_last_error(ctx) gives a ctx-owned message.
+ *   - field elements are little-endian uint64, canonical (< p = 2^64 - 2^32 + 1), in and out.
+ *   - pointers named d_* are device (HBM) pointers valid on the ctx's GPU; h_* are host.
+ *   - one glp_ctx per GPU per process; a ctx is not thread-safe.  Work is enqueued on the
+ *     ctx's HIP stream; functions without an _async suffix return after enqueueing and the
+ *     results are ordered on that stream (call glp_sync before reading them on the host).
+ *   - there is NO CPU fallback: without a usable gfx950 device glp_create fails.
+ */
+#ifndef GLPROVER_H
+#define GLPROVER_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLP_OK 0
+#define GLP_E_INVALID -1     /* bad argument */
+#define GLP_E_NODEVICE -2    /* no usable HIP device */
+#define GLP_E_HIP -3         /* HIP runtime error (see glp_last_error) */
+#define GLP_E_NOMEM -4
+#define GLP_E_UNSUPPORTED -5
+#define GLP_E_STATE -6       /* e.g. Poseidon constants not set */
+
+#define GLP_NTT_INVERSE 1u   /* inverse transform, scaled by 1/n */
+#define GLP_NTT_BITREV 2u    /* write outputs in bit-reversed index order */
+
+typedef struct glp_ctx glp_ctx;
+
+/* ---- context, memory, stream ------------------------------------------------------ */
+int glp_create(glp_ctx** out, int device_id);
+void glp_destroy(glp_ctx* ctx);
+const char* glp_last_error(const glp_ctx* ctx);
+const char* glp_version(void);
+int glp_alloc(glp_ctx* ctx, void** d_ptr, size_t bytes);
+int glp_free(glp_ctx* ctx, void* d_ptr);
+int glp_h2d(glp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);  /* synchronous */
+int glp_d2h(glp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);  /* synchronous */
+int glp_sync(glp_ctx* ctx);
+/* adopt an external hipStream_t (e.g. torch's current stream); NULL restores the ctx's own */
+int glp_set_stream(glp_ctx* ctx, void* hip_stream);
+/* HIP-event timer on the ctx's stream: start, enqueue work, stop -> elapsed milliseconds */
+int glp_timer_start(glp_ctx* ctx);
+int glp_timer_stop(glp_ctx* ctx, float* ms);
+
+/* ---- NTT / LDE (upstream names recalled: plonky2_field::fft::
+ *      fft / ifft / coset_fft, PolynomialCoeffs::lde, fri::oracle::PolynomialBatch) ------ */
+/* in place, natural order in and out:  X[k] = sum_j x[j] w_n^{jk},  w_n = 7^((p-1)/n) */
+int glp_ntt(glp_ctx* ctx, uint64_t* d_io, uint32_t log_n, uint32_t batch, int inverse);
+/* general form: src may equal dst; poly strides in elements (>= n); flags = GLP_NTT_* */
+int glp_ntt_ex(glp_ctx* ctx, const uint64_t* d_src, uint64_t* d_dst, uint32_t log_n, uint32_t batch,
+               uint64_t src_poly_stride, uint64_t dst_poly_stride, uint32_t flags);
+/* coefficients [batch][n] -> evaluations [batch][n << rate_bits] on the coset shift*<w>:
+ * zero-pad, scale coefficient j by shift^j, forward NTT.  flags: GLP_NTT_BITREV or 0 */
+int glp_lde_coset(glp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_out, uint32_t log_n, uint32_t rate_bits,
+                  uint32_t batch, uint64_t shift, uint32_t flags);
+/* [rows][cols] -> [cols][rows] (polynomial-major <-> leaf-major) */
+int glp_transpose(glp_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint64_t rows, uint64_t cols);
+/* force the pass structure of subsequent NTTs of size 2^log_n ("r:c,r:c,..." log2 radix :
+ * log2 columns per pass; NULL/"" = default heuristic).  Tuning/benchmark aid. */
+int glp_ntt_set_plan(glp_ctx* ctx, uint32_t log_n, const char* plan);
+/* describe the plan that would be used (for logs): writes a NUL-terminated string */
+int glp_ntt_describe_plan(glp_ctx* ctx, uint32_t log_n, uint32_t flags, char* buf, size_t buf_len);
+/* per-pass kernel times (ms) of the LAST glp_ntt*_ call when profiling is on; n_out <= 4 */
+int glp_set_profiling(glp_ctx* ctx, int on);
+int glp_last_pass_ms(glp_ctx* ctx, float* ms, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLPROVER_H */

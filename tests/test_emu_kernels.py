@@ -1,0 +1,82 @@
+"""The product's kernel bodies + host planning run on the CPU (tests/emu) and compared
+bit-for-bit with the oracle.  This is the pre-GPU gate for index arithmetic, LDS sizing and
+barrier placement; the GPU parity tests proper are in test_gpu_*.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import P, ptr, rand_field
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_product_field_arithmetic_vs_golden(emu):
+    with open(os.path.join(G, "field.json")) as f:
+        fld = json.load(f)
+    for a, b, s, d, m in fld["binary"]:
+        a, b = int(a), int(b)
+        assert emu.emu_gl_add(a, b) == int(s)
+        assert emu.emu_gl_sub(a, b) == int(d)
+        assert emu.emu_gl_mul(a, b) == int(m)
+    for a, s, r in fld["pow2"]:
+        assert emu.emu_gl_mul_pow2(int(a), s) == int(r), (a, s)
+    # reduce128 on arbitrary (non-product) inputs
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        hi, lo = int(rng.integers(0, 2**63)) * 2 + 1, int(rng.integers(0, 2**63)) * 2
+        assert emu.emu_gl_reduce128(hi, lo) == ((hi << 64) | lo) % P
+    for hi, lo in ((2**64 - 1, 2**64 - 1), (2**64 - 1, 0), (0, 2**64 - 1), (2**32 - 1, P), (P, P)):
+        assert emu.emu_gl_reduce128(hi, lo) == ((hi << 64) | lo) % P
+
+
+CASES = [
+    # log_n, batch, inverse, bitrev, plan, in_place
+    (0, 3, 0, 0, None, True), (1, 3, 0, 0, None, True), (3, 5, 0, 0, None, True), (5, 3, 1, 1, None, True),
+    (6, 3, 0, 0, None, True), (7, 40, 1, 0, None, True), (8, 2, 0, 0, None, False), (9, 9, 0, 1, None, True),
+    (10, 2, 1, 1, None, True), (11, 3, 0, 0, None, True), (12, 1, 0, 0, None, True), (12, 3, 1, 1, None, False),
+    (13, 1, 0, 0, None, True), (14, 2, 1, 0, None, False), (15, 1, 0, 1, None, True), (16, 2, 1, 1, None, True),
+    (16, 1, 0, 0, "8:4,8:4", True), (16, 1, 0, 0, "10:2,6:4", False), (18, 1, 0, 0, "6:4,6:4,6:4", True),
+    (18, 1, 1, 0, "6:4,6:4,6:4", False), (18, 1, 0, 1, "6:4,6:4,6:4", True), (17, 1, 0, 0, "6:3,11:3", True),
+]
+
+
+@pytest.mark.parametrize("log_n,batch,inv,rev,plan,in_place", CASES)
+def test_emulated_ntt_vs_oracle(emu, oracle, log_n, batch, inv, rev, plan, in_place):
+    rng = np.random.default_rng(1000 + log_n * 7 + batch)
+    n = 1 << log_n
+    x = rand_field(rng, (batch, n))
+    if batch > 1:
+        x[0, :] = P - 1          # extreme values
+        x[1, :] = 0
+    ref = x.copy()
+    if log_n > 0:
+        oracle.orc_ntt(ptr(ref), log_n, batch, inv)
+        if rev:
+            oracle.orc_bitrev_rows(ptr(ref), log_n, batch)
+    src = x.copy()
+    dst = src if in_place else np.zeros_like(x)
+    if log_n == 0:
+        pytest.skip("size-1 transform is a copy handled on the host side of the C ABI")
+    rc = emu.emu_ntt(ptr(src), ptr(dst), n, n, log_n, batch, inv, rev, plan.encode() if plan else None)
+    assert rc == 0
+    assert np.array_equal(dst, ref)
+    if not in_place:
+        assert np.array_equal(src, x), "out-of-place transform must not modify its source"
+
+
+def test_emulated_ntt_strided_batch(emu, oracle):
+    """polynomials embedded in wider rows (stride > n) on both sides"""
+    rng = np.random.default_rng(5)
+    log_n, batch, n = 10, 3, 1024
+    x = rand_field(rng, (batch, n))
+    src = np.full((batch, n + 24), 0xDEAD, dtype=np.uint64)
+    src[:, :n] = x
+    dst = np.full((batch, n + 8), 0xBEEF, dtype=np.uint64)
+    rc = emu.emu_ntt(ptr(src), ptr(dst), n + 24, n + 8, log_n, batch, 0, 0, None)
+    assert rc == 0
+    ref = x.copy()
+    oracle.orc_ntt(ptr(ref), log_n, batch, 0)
+    assert np.array_equal(dst[:, :n], ref)
+    assert np.all(dst[:, n:] == 0xBEEF)

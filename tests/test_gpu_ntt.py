@@ -1,0 +1,177 @@
+"""GPU parity tests for the NTT/LDE path: the HIP kernels, called through the C ABI,
+against the CPU oracle on the same seeded inputs, against the committed golden vectors,
+and — at BASELINE.json sizes — through size-independent properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import P, ptr, rand_field
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def oracle_ntt(oracle, x, inv=0, rev=0):
+    ref = np.ascontiguousarray(x).copy()
+    batch, n = ref.shape
+    log_n = n.bit_length() - 1
+    if log_n:
+        oracle.orc_ntt(ptr(ref), log_n, batch, inv)
+        if rev:
+            oracle.orc_bitrev_rows(ptr(ref), log_n, batch)
+    return ref
+
+
+def test_golden_vectors(prover):
+    with open(os.path.join(G, "ntt.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        x = np.array([int(v) for v in c["x"]], dtype=np.uint64)
+        assert np.array_equal(prover.fft(x), np.array([int(v) for v in c["fwd"]], dtype=np.uint64)), c["log_n"]
+        assert np.array_equal(prover.ifft(x), np.array([int(v) for v in c["inv"]], dtype=np.uint64)), c["log_n"]
+    with open(os.path.join(G, "lde.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        coeffs = np.array([int(v) for v in c["coeffs"]], dtype=np.uint64)
+        want = np.array([int(v) for v in c["values"]], dtype=np.uint64)
+        assert np.array_equal(prover.lde(coeffs, c["rate_bits"], int(c["shift"])), want)
+
+
+@pytest.mark.parametrize("log_n", list(range(0, 21)))
+def test_every_size_vs_oracle(prover, oracle, pkg, log_n):
+    rng = np.random.default_rng(100 + log_n)
+    batch = 3 if log_n <= 16 else 1
+    x = rand_field(rng, (batch, 1 << log_n))
+    x[0, :] = P - 1
+    for inv in (0, 1):
+        for rev in (0, 1):
+            d = prover.to_device(x)
+            prover.ntt_ex(d, d, log_n, batch, flags=inv * pkg.NTT_INVERSE + rev * pkg.NTT_BITREV)
+            got = d.download(x.shape)
+            d.free()
+            assert np.array_equal(got, oracle_ntt(oracle, x, inv, rev)), (log_n, inv, rev)
+
+
+PLANS = [(16, "8:4,8:4"), (16, "10:2,6:4"), (16, "6:6,10:4"), (18, "6:4,6:4,6:4"), (18, "9:3,9:3"), (20, "10:4,10:4"),
+         (20, "10:3,10:3"), (20, "7:5,7:5,6:6"), (20, "12:2,8:4"), (20, "8:4,12:2"), (22, "11:3,11:3"), (22, "8:4,7:5,7:5"),
+         (22, "12:2,10:4")]
+
+
+@pytest.mark.parametrize("log_n,plan", PLANS)
+def test_alternative_plans_vs_oracle(prover, oracle, pkg, log_n, plan):
+    """every pass structure must give the same bits (natural, bit-reversed, inverse)"""
+    rng = np.random.default_rng(log_n * 31 + len(plan))
+    x = rand_field(rng, (1, 1 << log_n))
+    prover.set_plan(log_n, plan)
+    try:
+        for inv, rev in ((0, 0), (1, 0), (0, 1)):
+            d = prover.to_device(x)
+            prover.ntt_ex(d, d, log_n, 1, flags=inv * pkg.NTT_INVERSE + rev * pkg.NTT_BITREV)
+            got = d.download(x.shape)
+            d.free()
+            assert np.array_equal(got, oracle_ntt(oracle, x, inv, rev)), (plan, inv, rev)
+    finally:
+        prover.set_plan(log_n, None)
+
+
+def test_out_of_place_and_strides(prover, oracle, pkg):
+    rng = np.random.default_rng(77)
+    log_n, batch, n = 14, 5, 1 << 14
+    x = rand_field(rng, (batch, n))
+    src = np.full((batch, n + 40), 0xDEAD, dtype=np.uint64)
+    src[:, :n] = x
+    dst = np.full((batch, n + 8), 0xBEEF, dtype=np.uint64)
+    ds, dd = prover.to_device(src), prover.to_device(dst)
+    prover.ntt_ex(ds, dd, log_n, batch, src_stride=n + 40, dst_stride=n + 8)
+    got = dd.download(dst.shape)
+    assert np.array_equal(got[:, :n], oracle_ntt(oracle, x))
+    assert np.all(got[:, n:] == 0xBEEF)
+    assert np.array_equal(ds.download(src.shape), src)
+    ds.free()
+    dd.free()
+
+
+def test_batch_chunking_small_scratch(prover, oracle, monkeypatch, pkg):
+    """a scratch cap smaller than the batch forces the chunked path"""
+    os.environ["GLP_SCRATCH_CAP_MB"] = "1"
+    pr = pkg.Prover(0)
+    del os.environ["GLP_SCRATCH_CAP_MB"]
+    rng = np.random.default_rng(9)
+    x = rand_field(rng, (7, 1 << 15))   # 256 KiB per poly, cap 1 MiB -> chunks of 4
+    assert np.array_equal(pr.fft(x), oracle_ntt(oracle, x))
+    pr.close()
+
+
+def test_lde_vs_oracle(prover, oracle):
+    rng = np.random.default_rng(11)
+    for log_n, rate_bits, batch in ((10, 3, 3), (13, 3, 2), (14, 1, 1), (5, 2, 4)):
+        c = rand_field(rng, (batch, 1 << log_n))
+        want = np.zeros((batch, 1 << (log_n + rate_bits)), dtype=np.uint64)
+        oracle.orc_lde_coset(ptr(c), ptr(want), log_n, rate_bits, batch, 7)
+        assert np.array_equal(prover.lde(c, rate_bits), want)
+        wrev = want.copy()
+        oracle.orc_bitrev_rows(ptr(wrev), log_n + rate_bits, batch)
+        assert np.array_equal(prover.lde(c, rate_bits, bitrev=True), wrev)
+
+
+def test_transpose(prover):
+    rng = np.random.default_rng(12)
+    for rows, cols in ((1, 1), (3, 5), (32, 32), (33, 65), (135, 1024), (1000, 7)):
+        m = rng.integers(0, P, size=(rows, cols), dtype=np.uint64)
+        assert np.array_equal(prover.transpose(m), m.T)
+
+
+def test_argument_errors(prover, pkg):
+    d = prover.alloc(1 << 16)
+    with pytest.raises(pkg.GlpError):
+        prover.ntt_ex(d, d, 33, 1)
+    with pytest.raises(pkg.GlpError):
+        prover.ntt_ex(d, d, 10, 2, src_stride=512, dst_stride=512)      # stride < n
+    with pytest.raises(pkg.GlpError):
+        prover.ntt_ex(d.ptr, d.ptr + 8, 10, 1)                          # partial overlap
+    with pytest.raises(pkg.GlpError):
+        prover.set_plan(16, "9:3,9:3")                                   # does not sum to 16
+    prover.ntt_ex(d, d, 10, 0)                                           # empty batch is a no-op
+    d.free()
+
+
+@pytest.mark.parametrize("log_n,batch", [(20, 8), (22, 2), (24, 1)])
+def test_full_size_properties(prover, pkg, log_n, batch):
+    """BASELINE sizes (oracle too slow to run many times): round trip, linearity, a delta
+    input (-> rows of w^k), and the constant input (-> n at index 0)."""
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    x = rand_field(rng, (batch, n))
+    d = prover.to_device(x)
+    prover.ntt_(d, log_n, batch)
+    fx = d.download(x.shape)
+    prover.ntt_(d, log_n, batch, inverse=True)
+    assert np.array_equal(d.download(x.shape), x), "ifft(fft(x)) != x"
+    # linearity: fft(x0 + x1) = fft(x0) + fft(x1) (batch >= 2) ; else vs scaled copy
+    if batch >= 2:
+        s = ((x[0].astype(object) + x[1].astype(object)) % P).astype(np.uint64)
+        fs = prover.fft(s)
+        want = ((fx[0].astype(object) + fx[1].astype(object)) % P).astype(np.uint64)
+        assert np.array_equal(fs, want)
+    # constant 1 -> (n, 0, 0, ...); delta at 1 -> w^k
+    one = np.ones(n, dtype=np.uint64)
+    f1 = prover.fft(one)
+    assert f1[0] == n % P and not f1[1:].any()
+    delta = np.zeros(n, dtype=np.uint64)
+    delta[1] = 1
+    fd = prover.fft(delta)
+    w = pow(7, (P - 1) >> log_n, P)
+    idx = [0, 1, 2, 3, n // 2, n // 2 + 1, n - 1, 12345 % n, (n // 3)]
+    for k in idx:
+        assert int(fd[k]) == pow(w, k, P), k
+    # bit-reversed output is the same multiset, permuted
+    db = prover.to_device(x[:1])
+    prover.ntt_ex(db, db, log_n, 1, flags=pkg.NTT_BITREV)
+    fb = db.download((1, n))[0]
+    db.free()
+    for k in idx:
+        r = int(format(k, f"0{log_n}b")[::-1], 2)
+        assert fb[r] == fx[0][k]
+    d.free()
