@@ -76,6 +76,46 @@ def cpu_baseline(log_n, seconds_target=15.0):
             "sample": f"{polys} forward NTTs of 2^{log_n} (16*n bytes each), OpenMP over the batch, {dt:.1f} s"}
 
 
+SWEEP = {
+    (20, 128): ["10:4,10:4", "10:3,10:3", "10:2,10:2", "8:4,12:2", "12:2,8:4", "7:5,7:5,6:6", "11:3,9:3", "9:3,11:3",
+                "9:4,11:3", "11:3,9:4", "12:1,8:4", "8:4,12:1", "10:3,10:4", "10:4,10:3"],
+    (22, 32): ["11:3,11:3", "11:2,11:2", "8:4,7:5,7:5", "10:4,12:2", "12:2,10:4", "10:3,12:2", "12:2,10:3", "12:1,10:3", "8:4,8:4,6:6"],
+    (24, 8): ["12:2,12:2", "12:1,12:1", "8:4,8:4,8:4", "12:2,6:4,6:4", "10:4,7:5,7:5", "6:6,6:6,12:2", "8:4,8:4,8:5", "9:4,9:4,6:6",
+              "12:2,12:1", "12:1,12:2"],
+    (20, 1): ["10:4,10:4", "10:3,10:3", "10:2,10:2", "8:4,12:2", "12:2,8:4", "7:5,7:5,6:6"],
+    (24, 1): ["12:2,12:2", "12:1,12:1", "8:4,8:4,8:4", "10:4,7:5,7:5"],
+}
+
+
+def sweep():
+    """tuning aid: one line per (size, plan) with total and per-pass HIP-event times"""
+    pkg = graft.load_package()
+    pr = pkg.Prover(0)
+    for (log_n, batch), plans in SWEEP.items():
+        n = 1 << log_n
+        d = pr.to_device(splitmix_fill(n * batch, 3).reshape(batch, n))
+        for plan in [None] + plans:
+            try:
+                pr.set_plan(log_n, plan)
+            except Exception as e:  # noqa: BLE001
+                print(json.dumps({"log_n": log_n, "batch": batch, "plan": plan, "error": str(e)}), flush=True)
+                continue
+            ms = time_ntt(pr, d, log_n, batch, steps=10, warmup=3)
+            pr.set_profiling(True)
+            acc = None
+            for _ in range(5):
+                pr.ntt_(d, log_n, batch)
+                pm = pr.last_pass_ms()
+                acc = pm if acc is None else [a + b for a, b in zip(acc, pm)]
+            pr.set_profiling(False)
+            print(json.dumps({"log_n": log_n, "batch": batch, "plan": pr.describe_plan(log_n), "ms": round(ms, 4),
+                              "gbps": round(16.0 * n * batch / ms / 1e6, 1), "pass_ms": [round(a / 5, 4) for a in acc]}),
+                  flush=True)
+        pr.set_plan(log_n, None)
+        d.free()
+    pr.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,8 +125,11 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-sizes", action="store_true", help="skip the 2^20/2^22/2^24 sweep")
+    ap.add_argument("--sweep", action="store_true", help="tuning aid: time alternative pass plans and exit")
     args = ap.parse_args()
 
+    if args.sweep:
+        return sweep()
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
