@@ -266,6 +266,97 @@ class Prover:
     def coset_fft(self, coeffs, shift=COSET_SHIFT):
         return self.lde(coeffs, 0, shift)
 
+    # ---- Poseidon / Merkle / FRI / SHA-2 (rows a4, a8, a9) -------------------------------
+    def set_poseidon_constants(self, rc, circ, diag):
+        rc = np.ascontiguousarray(rc, dtype=np.uint64)
+        circ = np.ascontiguousarray(circ, dtype=np.uint64)
+        diag = np.ascontiguousarray(diag, dtype=np.uint64)
+        self._chk(self.lib.glp_set_poseidon_constants(self.ctx, rc.ctypes.data, rc.size, circ.ctypes.data, diag.ctypes.data),
+                  "glp_set_poseidon_constants")
+
+    def poseidon_permute_(self, d_states, n):
+        self._chk(self.lib.glp_poseidon_permute(self.ctx, _ptr(d_states), n), "glp_poseidon_permute")
+
+    def poseidon_permute(self, states):
+        s = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 12)
+        d = self.to_device(s)
+        self.poseidon_permute_(d, s.shape[0])
+        out = d.download(s.shape)
+        d.free()
+        return out
+
+    @staticmethod
+    def merkle_digest_len(log_leaves, cap_h):
+        return 4 * ((2 << log_leaves) - (1 << cap_h))
+
+    def merkle_(self, d_src, leaf_len, log_leaves, cap_h, d_digests, poly_major=False, poly_stride=None, want_cap=True):
+        cap = np.zeros((1 << cap_h, 4), dtype=np.uint64) if want_cap else None
+        capp = cap.ctypes.data if want_cap else None
+        if poly_major:
+            self._chk(self.lib.glp_merkle_from_polys(self.ctx, _ptr(d_src), poly_stride or (1 << log_leaves), leaf_len, log_leaves,
+                                                     cap_h, _ptr(d_digests), capp), "glp_merkle_from_polys")
+        else:
+            self._chk(self.lib.glp_merkle(self.ctx, _ptr(d_src), leaf_len, log_leaves, cap_h, _ptr(d_digests), capp), "glp_merkle")
+        return cap
+
+    def merkle_tree(self, leaves, cap_h, poly_major=False):
+        """leaves [n_leaves][leaf_len] (or, poly_major, [leaf_len][n_leaves]) -> (digests, cap)"""
+        a = np.ascontiguousarray(leaves, dtype=np.uint64)
+        n_leaves, leaf_len = (a.shape[1], a.shape[0]) if poly_major else a.shape
+        log_leaves = n_leaves.bit_length() - 1
+        assert 1 << log_leaves == n_leaves
+        d = self.to_device(a)
+        nd = self.merkle_digest_len(log_leaves, cap_h)
+        dd = self.alloc(nd * 8)
+        cap = self.merkle_(d, leaf_len, log_leaves, cap_h, dd, poly_major=poly_major)
+        dig = dd.download((nd // 4, 4))
+        d.free()
+        dd.free()
+        return dig, cap
+
+    def fri_fold2(self, evals, shift, beta):
+        """evals [n][2] in bit-reversed order over shift*<w_n> -> [n/2][2]"""
+        e = np.ascontiguousarray(evals, dtype=np.uint64)
+        n = e.shape[0]
+        log_n = n.bit_length() - 1
+        b = np.ascontiguousarray(beta, dtype=np.uint64)
+        d = self.to_device(e)
+        o = self.alloc(max(8, e.nbytes // 2))
+        self._chk(self.lib.glp_fri_fold2(self.ctx, d.ptr, o.ptr, log_n, shift, b.ctypes.data), "glp_fri_fold2")
+        out = o.download((n // 2, 2))
+        d.free()
+        o.free()
+        return out
+
+    def sha256_trace(self, padded, blocks_per_msg, want_trace=True):
+        """padded: [n_msgs][blocks_per_msg*64] uint8 -> (digests [n][8] u32, trace [n][blocks][576] u32)"""
+        m = np.ascontiguousarray(padded, dtype=np.uint8)
+        n = m.shape[0]
+        d = self.to_device(m)
+        dd = self.alloc(max(8, n * 32))
+        dt = self.alloc(n * blocks_per_msg * 576 * 4) if want_trace and n else None
+        self._chk(self.lib.glp_sha256_trace(self.ctx, d.ptr, n, blocks_per_msg, dd.ptr, dt.ptr if dt else None), "glp_sha256_trace")
+        dig = dd.download((n, 8), np.uint32)
+        tr = dt.download((n, blocks_per_msg, 576), np.uint32) if dt else None
+        for b in (d, dd, dt):
+            if b:
+                b.free()
+        return dig, tr
+
+    def sha512_trace(self, padded, blocks_per_msg, want_trace=True):
+        m = np.ascontiguousarray(padded, dtype=np.uint8)
+        n = m.shape[0]
+        d = self.to_device(m)
+        dd = self.alloc(max(8, n * 64))
+        dt = self.alloc(n * blocks_per_msg * 720 * 8) if want_trace and n else None
+        self._chk(self.lib.glp_sha512_trace(self.ctx, d.ptr, n, blocks_per_msg, dd.ptr, dt.ptr if dt else None), "glp_sha512_trace")
+        dig = dd.download((n, 8), np.uint64)
+        tr = dt.download((n, blocks_per_msg, 720), np.uint64) if dt else None
+        for b in (d, dd, dt):
+            if b:
+                b.free()
+        return dig, tr
+
     def transpose(self, mat):
         m = np.ascontiguousarray(mat, dtype=np.uint64)
         rows, cols = m.shape
@@ -276,3 +367,57 @@ class Prover:
         d_in.free()
         d_out.free()
         return out
+
+
+def sha_pad(msg: bytes, block: int, blocks: int = None) -> bytes:
+    """FIPS 180-4 padding to whole blocks (block = 64 for SHA-256, 128 for SHA-512); when
+    `blocks` is given the message must fit exactly that many blocks (fixed-shape batches)."""
+    lenbytes = 8 if block == 64 else 16
+    need = (len(msg) + 1 + lenbytes + block - 1) // block
+    if blocks is not None:
+        assert need == blocks, "message does not pad to the requested number of blocks"
+    pad = need * block - len(msg) - 1 - lenbytes
+    return msg + b"\x80" + b"\x00" * pad + (8 * len(msg)).to_bytes(lenbytes, "big")
+
+
+class PolynomialBatch:
+    """Commitment to a batch of polynomials (upstream name recalled:
+    plonky2::fri::oracle::PolynomialBatch, file:line NONE — absent from the mount).
+
+    from_values: values on <w_n> -> coefficients (inverse NTT) -> from_coeffs.
+    from_coeffs: coset LDE by 2^rate_bits on shift*<w_N> (N = n << rate_bits), stored
+    polynomial-major [n_polys][N] with the evaluation index BIT-REVERSED, then a Poseidon
+    Merkle tree whose leaf i is column i of that matrix (hashed straight from the
+    polynomial-major layout: no transpose pass).  Everything stays resident in HBM."""
+
+    def __init__(self, prover, n_polys, log_n, rate_bits, cap_height):
+        self.prover, self.n_polys, self.log_n, self.rate_bits, self.cap_height = prover, n_polys, log_n, rate_bits, cap_height
+        self.coeffs = self.lde = self.digests = None
+        self.cap = None
+
+    @classmethod
+    def from_coeffs(cls, prover, d_coeffs, n_polys, log_n, rate_bits, cap_height, keep_coeffs=True):
+        self = cls(prover, n_polys, log_n, rate_bits, cap_height)
+        log_N = log_n + rate_bits
+        self.coeffs = d_coeffs if keep_coeffs else None
+        self.lde = prover.alloc(n_polys * (8 << log_N))
+        prover.lde_coset_(d_coeffs, self.lde, log_n, rate_bits, n_polys, COSET_SHIFT, NTT_BITREV)
+        self.digests = prover.alloc(8 * Prover.merkle_digest_len(log_N, cap_height))
+        self.cap = prover.merkle_(self.lde, n_polys, log_N, cap_height, self.digests, poly_major=True, poly_stride=1 << log_N)
+        return self
+
+    @classmethod
+    def from_values(cls, prover, values, rate_bits, cap_height):
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        n_polys, n = v.shape
+        log_n = n.bit_length() - 1
+        assert 1 << log_n == n
+        d = prover.to_device(v)
+        prover.ntt_(d, log_n, n_polys, inverse=True)
+        return cls.from_coeffs(prover, d, n_polys, log_n, rate_bits, cap_height)
+
+    def free(self):
+        for b in (self.coeffs, self.lde, self.digests):
+            if isinstance(b, DeviceBuffer):
+                b.free()
+        self.coeffs = self.lde = self.digests = None

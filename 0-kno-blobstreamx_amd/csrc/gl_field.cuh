@@ -24,6 +24,16 @@ typedef uint32_t u32;
 #define GL_P 0xFFFFFFFF00000001ULL
 #define GL_EPS 0xFFFFFFFFULL  // 2^64 mod p = 2^32 - 1
 
+// compile-time unrolled loop: f(glp_ic<I>{}) for I in [I0, N)
+template <int V> struct glp_ic { static constexpr int value = V; };
+template <int I, int N, class F>
+GL_HD void glp_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(glp_ic<I>{});
+        glp_static_for<I + 1, N>(f);
+    }
+}
+
 GL_HD u64 gl_add(u64 a, u64 b) {
     u64 s = a + b;
     u64 t = s + GL_EPS;  // s - p (mod 2^64)

@@ -79,6 +79,14 @@ static int ensure_table(glp_ctx* c, int log_N, int inv) {
     return GLP_OK;
 }
 
+int glp_ntt_table(glp_ctx* c, int log_N, int inv, const u64** lo, const u64** hi) {
+    int rc = ensure_table(c, log_N, inv);
+    if (rc != GLP_OK) return rc;
+    const glp_table& t = c->tables[log_N * 2 + (inv ? 1 : 0)];
+    *lo = t.lo; *hi = t.hi;
+    return GLP_OK;
+}
+
 namespace {
 struct HipBackend {
     glp_ctx* c;

@@ -1,0 +1,271 @@
+// hash_kernels.cuh — Poseidon-Goldilocks permutation (width 12, x^7, 4 + 22 + 4 rounds),
+// overwrite-mode sponge (rate 8), 2-to-1 compression, Merkle levels; arity-2 FRI fold;
+// SHA-256 / SHA-512 compression with per-round trace.   SURVEY.md §8a rows a4, a8, a9.
+// Upstream names (recalled, unverified; reference file:line NONE — the mount is empty):
+// plonky2::hash::poseidon::Poseidon::poseidon, hashing::hash_n_to_hash_no_pad,
+// PoseidonHash::two_to_one, merkle_tree::MerkleTree::new, fri::prover (fold), curta SHA chips.
+//
+// Round constants and the MDS vectors are INJECTED (glp_set_poseidon_constants): the
+// library ships none, so digests are "self-consistent, not plonky2-compatible" until the
+// real table is supplied.
+//
+// One permutation per work-item, the 12-word state in 24 VGPRs; constants are read with
+// wave-uniform addresses (scalar loads).  When every MDS entry is < 2^32 and their sum is
+// < 2^32 (true for any small-integer MDS such as plonky2's), a row of the MDS layer is two
+// 64-bit accumulators of 32x32 products (lo halves and hi halves of the state) and ONE
+// 128-bit reduction, instead of twelve full field multiplications.
+//
+// Plain HIP C++ without AMD builtins: tests/emu runs these bodies on the CPU.
+#pragma once
+#include "gl_field.cuh"
+
+#define GLP_POS_WIDTH 12
+#define GLP_POS_RATE 8
+#define GLP_POS_FULL_HALF 4
+#define GLP_POS_PARTIAL 22
+#define GLP_POS_ROUNDS 30
+
+struct GlpPoseidonConsts {
+    const u64* rc;     // [30][12]
+    const u64* circ;   // [12]
+    const u64* diag;   // [12]
+};
+
+#define glp_hfor glp_static_for
+
+GL_HD u64 glp_sbox7(u64 x) {
+    u64 x2 = gl_mul(x, x), x3 = gl_mul(x2, x), x4 = gl_mul(x2, x2);
+    return gl_mul(x3, x4);
+}
+
+// s <- MDS * s  with  row r = sum_i s[(i + r) % 12] * circ[i] + s[r] * diag[r]
+template <bool SMALL>
+GL_HD void glp_mds_layer(u64 (&s)[12], const u64* __restrict__ circ, const u64* __restrict__ diag) {
+    u64 out[12];
+    if constexpr (SMALL) {
+        u32 lo[12], hi[12], c[12], dg[12];
+        glp_hfor<0, 12>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32);
+            c[i] = (u32)circ[i]; dg[i] = (u32)diag[i];
+        });
+        glp_hfor<0, 12>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            u64 al = (u64)lo[r] * dg[r], ah = (u64)hi[r] * dg[r];
+            glp_hfor<0, 12>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                al += (u64)lo[(i + r) % 12] * c[i];
+                ah += (u64)hi[(i + r) % 12] * c[i];
+            });
+            // value = al + ah * 2^32  (al, ah < 2^64)
+            u64 l = al + (ah << 32);
+            u64 h = (ah >> 32) + (l < al ? 1ull : 0ull);
+            out[r] = gl_reduce128(h, l);
+        });
+    } else {
+        glp_hfor<0, 12>([&](auto r_) {
+            constexpr int r = decltype(r_)::value;
+            u64 acc = gl_mul(s[r], diag[r]);
+            glp_hfor<0, 12>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                acc = gl_add(acc, gl_mul(s[(i + r) % 12], circ[i]));
+            });
+            out[r] = acc;
+        });
+    }
+    glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = out[i]; });
+}
+
+template <bool SMALL>
+GL_HD void glp_poseidon_permute(u64 (&s)[12], const GlpPoseidonConsts& k) {
+    int rnd = 0;
+    for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
+        glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = glp_sbox7(gl_add(s[i], k.rc[rnd * 12 + i])); });
+        glp_mds_layer<SMALL>(s, k.circ, k.diag);
+    }
+    for (int r = 0; r < GLP_POS_PARTIAL; r++, rnd++) {
+        glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = gl_add(s[i], k.rc[rnd * 12 + i]); });
+        s[0] = glp_sbox7(s[0]);
+        glp_mds_layer<SMALL>(s, k.circ, k.diag);
+    }
+    for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
+        glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = glp_sbox7(gl_add(s[i], k.rc[rnd * 12 + i])); });
+        glp_mds_layer<SMALL>(s, k.circ, k.diag);
+    }
+}
+
+// n independent permutations, in place, states [n][12]
+template <bool SMALL>
+__global__ void __launch_bounds__(256) glp_poseidon_permute_kernel(u64* states, u64 n, GlpPoseidonConsts k) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 s[12];
+    glp_hfor<0, 12>([&](auto j_) { constexpr int j = decltype(j_)::value; s[j] = states[i * 12 + j]; });
+    glp_poseidon_permute<SMALL>(s, k);
+    glp_hfor<0, 12>([&](auto j_) { constexpr int j = decltype(j_)::value; states[i * 12 + j] = s[j]; });
+}
+
+// Leaf digests.  Leaf i has leaf_len elements:
+//   POLY_MAJOR: element j of leaf i = src[j * stride + i]   (columns of the LDE; coalesced over i)
+//   else      : element j of leaf i = src[i * stride + j]   (leaf-major rows)
+// leaf_len <= 4: the digest is the zero-padded leaf itself (hash_or_noop); otherwise the
+// overwrite-mode sponge with rate 8.
+template <bool SMALL, bool POLY_MAJOR>
+__global__ void __launch_bounds__(256) glp_hash_leaves_kernel(const u64* __restrict__ src, u64 stride, u32 leaf_len,
+                                                              u64 n_leaves, u64* __restrict__ digests, GlpPoseidonConsts k) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    auto at = [&](u32 j) -> u64 { return POLY_MAJOR ? src[(u64)j * stride + i] : src[i * stride + j]; };
+    u64 s[12];
+    glp_hfor<0, 12>([&](auto j_) { constexpr int j = decltype(j_)::value; s[j] = 0; });
+    if (leaf_len <= 4) {
+        glp_hfor<0, 4>([&](auto j_) { constexpr int j = decltype(j_)::value; if ((u32)j < leaf_len) s[j] = at(j); });
+    } else {
+        u32 off = 0;
+        for (; off + GLP_POS_RATE <= leaf_len; off += GLP_POS_RATE) {
+            glp_hfor<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; s[j] = at(off + j); });
+            glp_poseidon_permute<SMALL>(s, k);
+        }
+        if (off < leaf_len) {
+            glp_hfor<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; if (off + j < leaf_len) s[j] = at(off + j); });
+            glp_poseidon_permute<SMALL>(s, k);
+        }
+    }
+    glp_hfor<0, 4>([&](auto j_) { constexpr int j = decltype(j_)::value; digests[i * 4 + j] = s[j]; });
+}
+
+// one Merkle level: cur[i] = two_to_one(prev[2i], prev[2i+1]), digests are 4 u64
+template <bool SMALL>
+__global__ void __launch_bounds__(256) glp_merkle_level_kernel(const u64* __restrict__ prev, u64* __restrict__ cur, u64 count,
+                                                               GlpPoseidonConsts k) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 s[12];
+    glp_hfor<0, 8>([&](auto j_) { constexpr int j = decltype(j_)::value; s[j] = prev[i * 8 + j]; });
+    glp_hfor<8, 12>([&](auto j_) { constexpr int j = decltype(j_)::value; s[j] = 0; });
+    glp_poseidon_permute<SMALL>(s, k);
+    glp_hfor<0, 4>([&](auto j_) { constexpr int j = decltype(j_)::value; cur[i * 4 + j] = s[j]; });
+}
+
+// ---- FRI arity-2 fold (row a8) -------------------------------------------------------------
+// evals [n][2] (extension elements) in bit-reversed order over shift*<w_n>; pair i =
+// (f(x), f(-x)) with x = shift * w^{rev(i)} (rev over log_n - 1 bits).
+//   out[i] = (f(x)+f(-x))/2 + beta * (f(x)-f(-x)) / (2x)
+// half_inv = 1/2, c = 1/(2*shift); iw_lo/iw_hi = two-level table of w_n^{-e}.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_fri_fold2_kernel(const u64* __restrict__ evals, u64* __restrict__ out, u32 log_n,
+                                                            u64 half_inv, u64 c, gl_ext2 beta, const u64* __restrict__ iw_lo,
+                                                            const u64* __restrict__ iw_hi) {
+    const u64 half = 1ull << (log_n - 1);
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    // bit reversal of i over (log_n - 1) bits, portable form (also runs under tests/emu)
+    u64 e = 0;
+    for (u32 b = 0; b + 1 < log_n; b++) e |= ((i >> b) & 1ull) << (log_n - 2 - b);
+    u64 xi = iw_lo[e & 4095u];
+    if (iw_hi) xi = gl_mul(xi, iw_hi[e >> 12]);
+    xi = gl_mul(xi, c);                                   // 1 / (2x)
+    const gl_ext2 f0{evals[4 * i], evals[4 * i + 1]}, f1{evals[4 * i + 2], evals[4 * i + 3]};
+    const gl_ext2 sum = gl_ext_scale(gl_ext_add(f0, f1), half_inv);
+    const gl_ext2 dif = gl_ext_scale(gl_ext_sub(f0, f1), xi);
+    const gl_ext2 r = gl_ext_add(sum, gl_ext_mul(beta, dif));
+    out[2 * i] = r.a;
+    out[2 * i + 1] = r.b;
+}
+
+// ---- SHA-2 witness traces (row a9) ---------------------------------------------------------
+GL_HD u32 glp_ror32(u32 x, int r) { return (x >> r) | (x << (32 - r)); }
+GL_HD u64 glp_ror64(u64 x, int r) { return (x >> r) | (x << (64 - r)); }
+
+// One work-item per message.  blocks: [n_msgs][blocks_per_msg][64] bytes, already padded.
+// digests [n_msgs][8] u32; trace (optional) [n_msgs][blocks][576]: w[64] then 64 x (a..h).
+// k256: the 64 round constants (device table, uniform reads).
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_sha256_trace_kernel(const uint8_t* __restrict__ blocks, u64 n_msgs, u32 bpm,
+                                                               u32* __restrict__ digests, u32* __restrict__ trace,
+                                                               const u32* __restrict__ k256) {
+    const u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_msgs) return;
+    u32 h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    for (u32 b = 0; b < bpm; b++) {
+        const uint8_t* p = blocks + (m * bpm + b) * 64;
+        u32* tr = trace ? trace + (m * bpm + b) * 576 : nullptr;
+        u32 w[16];
+        for (int i = 0; i < 16; i++) w[i] = ((u32)p[4 * i] << 24) | ((u32)p[4 * i + 1] << 16) | ((u32)p[4 * i + 2] << 8) | p[4 * i + 3];
+        u32 s0 = h[0], s1 = h[1], s2 = h[2], s3 = h[3], s4 = h[4], s5 = h[5], s6 = h[6], s7 = h[7];
+        #pragma unroll
+        for (int i = 0; i < 64; i++) {
+            u32 wi;
+            if (i < 16) wi = w[i];
+            else {
+                const u32 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+                const u32 g0 = glp_ror32(w15, 7) ^ glp_ror32(w15, 18) ^ (w15 >> 3);
+                const u32 g1 = glp_ror32(w2, 17) ^ glp_ror32(w2, 19) ^ (w2 >> 10);
+                wi = w[i & 15] + g0 + w[(i - 7) & 15] + g1;
+                w[i & 15] = wi;
+            }
+            if (tr) tr[i] = wi;
+            const u32 S1 = glp_ror32(s4, 6) ^ glp_ror32(s4, 11) ^ glp_ror32(s4, 25);
+            const u32 ch = (s4 & s5) ^ (~s4 & s6);
+            const u32 t1 = s7 + S1 + ch + k256[i] + wi;
+            const u32 S0 = glp_ror32(s0, 2) ^ glp_ror32(s0, 13) ^ glp_ror32(s0, 22);
+            const u32 mj = (s0 & s1) ^ (s0 & s2) ^ (s1 & s2);
+            const u32 t2 = S0 + mj;
+            s7 = s6; s6 = s5; s5 = s4; s4 = s3 + t1; s3 = s2; s2 = s1; s1 = s0; s0 = t1 + t2;
+            if (tr) {
+                u32* q = tr + 64 + 8 * i;
+                q[0] = s0; q[1] = s1; q[2] = s2; q[3] = s3; q[4] = s4; q[5] = s5; q[6] = s6; q[7] = s7;
+            }
+        }
+        h[0] += s0; h[1] += s1; h[2] += s2; h[3] += s3; h[4] += s4; h[5] += s5; h[6] += s6; h[7] += s7;
+    }
+    for (int i = 0; i < 8; i++) digests[m * 8 + i] = h[i];
+}
+
+// 128-byte blocks; digests [n_msgs][8] u64; trace [n_msgs][blocks][720]: w[80] then 80 x (a..h)
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_sha512_trace_kernel(const uint8_t* __restrict__ blocks, u64 n_msgs, u32 bpm,
+                                                               u64* __restrict__ digests, u64* __restrict__ trace,
+                                                               const u64* __restrict__ k512) {
+    const u64 m = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_msgs) return;
+    u64 h[8] = {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+                0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+    for (u32 b = 0; b < bpm; b++) {
+        const uint8_t* p = blocks + (m * bpm + b) * 128;
+        u64* tr = trace ? trace + (m * bpm + b) * 720 : nullptr;
+        u64 w[16];
+        for (int i = 0; i < 16; i++) {
+            u64 v = 0;
+            for (int j = 0; j < 8; j++) v = (v << 8) | p[8 * i + j];
+            w[i] = v;
+        }
+        u64 s0 = h[0], s1 = h[1], s2 = h[2], s3 = h[3], s4 = h[4], s5 = h[5], s6 = h[6], s7 = h[7];
+        #pragma unroll
+        for (int i = 0; i < 80; i++) {
+            u64 wi;
+            if (i < 16) wi = w[i];
+            else {
+                const u64 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+                const u64 g0 = glp_ror64(w15, 1) ^ glp_ror64(w15, 8) ^ (w15 >> 7);
+                const u64 g1 = glp_ror64(w2, 19) ^ glp_ror64(w2, 61) ^ (w2 >> 6);
+                wi = w[i & 15] + g0 + w[(i - 7) & 15] + g1;
+                w[i & 15] = wi;
+            }
+            if (tr) tr[i] = wi;
+            const u64 S1 = glp_ror64(s4, 14) ^ glp_ror64(s4, 18) ^ glp_ror64(s4, 41);
+            const u64 ch = (s4 & s5) ^ (~s4 & s6);
+            const u64 t1 = s7 + S1 + ch + k512[i] + wi;
+            const u64 S0 = glp_ror64(s0, 28) ^ glp_ror64(s0, 34) ^ glp_ror64(s0, 39);
+            const u64 mj = (s0 & s1) ^ (s0 & s2) ^ (s1 & s2);
+            const u64 t2 = S0 + mj;
+            s7 = s6; s6 = s5; s5 = s4; s4 = s3 + t1; s3 = s2; s2 = s1; s1 = s0; s0 = t1 + t2;
+            if (tr) {
+                u64* q = tr + 80 + 8 * i;
+                q[0] = s0; q[1] = s1; q[2] = s2; q[3] = s3; q[4] = s4; q[5] = s5; q[6] = s6; q[7] = s7;
+            }
+        }
+        h[0] += s0; h[1] += s1; h[2] += s2; h[3] += s3; h[4] += s4; h[5] += s5; h[6] += s6; h[7] += s7;
+    }
+    for (int i = 0; i < 8; i++) digests[m * 8 + i] = h[i];
+}

@@ -29,15 +29,6 @@
 #include "gl_field.cuh"
 #include "ntt_plan.h"
 
-template <int V> struct glp_ic { static constexpr int value = V; };
-template <int I, int N, class F>
-GL_HD void glp_static_for(F&& f) {
-    if constexpr (I < N) {
-        f(glp_ic<I>{});
-        glp_static_for<I + 1, N>(f);
-    }
-}
-
 constexpr int glp_bitrev_c(int v, int bits) {
     int r = 0;
     for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);

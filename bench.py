@@ -116,6 +116,49 @@ def sweep():
     pr.close()
 
 
+def hash_bench():
+    """tuning aid: Poseidon permutation rate and the configs[1]-shaped commitment stages"""
+    import importlib
+    pkg = graft.load_package()
+    pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    pr = pkg.Prover(0)
+    rc, circ, diag = pc.default_constants()
+    pr.set_poseidon_constants(np.array(rc, dtype=np.uint64), np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64))
+    n = 1 << 22
+    d = pr.to_device(splitmix_fill(n * 12, 1))
+    pr.poseidon_permute_(d, n)
+    pr.sync()
+    pr.timer_start()
+    for _ in range(5):
+        pr.poseidon_permute_(d, n)
+    ms = pr.timer_stop() / 5
+    print(json.dumps({"stage": "poseidon_permute", "n": n, "ms": round(ms, 3), "Mperm_per_s": round(n / ms / 1e3, 1)}), flush=True)
+    d.free()
+    for n_polys, log_n, rate_bits in ((128, 17, 3), (135, 20, 3)):
+        N = 1 << (log_n + rate_bits)
+        co = pr.to_device(splitmix_fill(n_polys << log_n, 2))
+        lde = pr.alloc(n_polys * N * 8)
+        dig = pr.alloc(8 * pkg.Prover.merkle_digest_len(log_n + rate_bits, 4))
+        res = {"stage": "from_coeffs", "n_polys": n_polys, "log_n": log_n, "rate_bits": rate_bits}
+        for name, fn in (("lde_bitrev_ms", lambda: pr.lde_coset_(co, lde, log_n, rate_bits, n_polys, 7, pkg.NTT_BITREV)),
+                         ("merkle_ms", lambda: pr.merkle_(lde, n_polys, log_n + rate_bits, 4, dig, poly_major=True, poly_stride=N,
+                                                          want_cap=False)),
+                         ("ifft_ms", lambda: pr.ntt_(co, log_n, n_polys, inverse=True))):
+            fn()
+            pr.sync()
+            pr.timer_start()
+            for _ in range(3):
+                fn()
+            res[name] = round(pr.timer_stop() / 3, 3)
+        perms = N * ((n_polys + 7) // 8) + N
+        res["merkle_Mperm_per_s"] = round(perms / res["merkle_ms"] / 1e3, 1)
+        res["lde_out_GBps"] = round(n_polys * N * 8 / res["lde_bitrev_ms"] / 1e6, 1)
+        print(json.dumps(res), flush=True)
+        for b in (co, lde, dig):
+            b.free()
+    pr.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,10 +169,13 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-sizes", action="store_true", help="skip the 2^20/2^22/2^24 sweep")
     ap.add_argument("--sweep", action="store_true", help="tuning aid: time alternative pass plans and exit")
+    ap.add_argument("--hash-bench", action="store_true", help="tuning aid: Poseidon / LDE / Merkle stage times and exit")
     args = ap.parse_args()
 
     if args.sweep:
         return sweep()
+    if args.hash_bench:
+        return hash_bench()
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))

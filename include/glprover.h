@@ -79,6 +79,44 @@ int glp_ntt_describe_plan(glp_ctx* ctx, uint32_t log_n, uint32_t flags, char* bu
 int glp_set_profiling(glp_ctx* ctx, int on);
 int glp_last_pass_ms(glp_ctx* ctx, float* ms, int* n_out);
 
+/* ---- Poseidon / Merkle (row a4; upstream names recalled: plonky2::hash::poseidon,
+ *      hashing::hash_n_to_hash_no_pad, PoseidonHash::two_to_one, merkle_tree::MerkleTree::new) */
+/* rc: 360 round constants (30 rounds x 12), mds_circ: 12, mds_diag: 12.  Must be called
+ * before any hashing entry point; the library ships no constants. */
+int glp_set_poseidon_constants(glp_ctx* ctx, const uint64_t* h_rc, size_t n_rc, const uint64_t* h_mds_circ,
+                               const uint64_t* h_mds_diag);
+/* n_states independent width-12 permutations, in place, [n_states][12] */
+int glp_poseidon_permute(glp_ctx* ctx, uint64_t* d_states, uint64_t n_states);
+/* d_leaves: [2^log_leaves][leaf_len] (leaf-major).  d_digests receives every level from
+ * the leaf digests down to the cap level: 4 * (2^(log_leaves+1) - 2^cap_h) u64.
+ * h_cap (may be NULL) receives the 2^cap_h cap digests (4 u64 each) — synchronous if given. */
+int glp_merkle(glp_ctx* ctx, const uint64_t* d_leaves, uint32_t leaf_len, uint32_t log_leaves, uint32_t cap_h,
+               uint64_t* d_digests, uint64_t* h_cap);
+/* same tree, but leaves given polynomial-major: d_polys [leaf_len][2^log_leaves]
+ * (leaf i = column i), so the LDE output is hashed without a transpose pass */
+int glp_merkle_from_polys(glp_ctx* ctx, const uint64_t* d_polys, uint64_t poly_stride, uint32_t leaf_len,
+                          uint32_t log_leaves, uint32_t cap_h, uint64_t* d_digests, uint64_t* h_cap);
+
+/* ---- FRI (row a8; upstream name recalled: plonky2::fri::prover) -------------------- */
+/* arity-2 fold of extension-field evaluations in bit-reversed order over shift*<w_{log_n}>:
+ * d_evals [n][2] -> d_out [n/2][2];  h_beta = 2 u64 */
+int glp_fri_fold2(glp_ctx* ctx, const uint64_t* d_evals, uint64_t* d_out, uint32_t log_n, uint64_t shift,
+                  const uint64_t* h_beta);
+
+/* ---- witness generation (rows a9; upstream names recalled: curta SHA-256/SHA-512 chips) */
+/* n_msgs messages, each already padded to blocks_per_msg 64-byte blocks, [n_msgs][blocks*64].
+ * d_digests: [n_msgs][8] u32 (big-endian words as u32).  d_trace (may be NULL):
+ * [n_msgs][blocks][576] u32 = 64 schedule words then 64x8 round states. */
+int glp_sha256_trace(glp_ctx* ctx, const uint8_t* d_blocks, uint64_t n_msgs, uint32_t blocks_per_msg,
+                     uint32_t* d_digests, uint32_t* d_trace);
+/* 128-byte blocks; digests [n_msgs][8] u64; trace [n_msgs][blocks][720] u64 */
+int glp_sha512_trace(glp_ctx* ctx, const uint8_t* d_blocks, uint64_t n_msgs, uint32_t blocks_per_msg,
+                     uint64_t* d_digests, uint64_t* d_trace);
+
+/* Multi-GPU (row a11 / SURVEY §8e): leaf subproofs shard one per GPU; the all-gather of the
+ * padded proof blobs is done by the host through torch.distributed (RCCL) — see bench.py /
+ * INTEGRATION.md — so the C ABI has no communicator entry point. */
+
 #ifdef __cplusplus
 }
 #endif

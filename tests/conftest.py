@@ -44,7 +44,39 @@ def oracle():
     lib.orc_bitrev_rows.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint64]
     lib.orc_lde_coset.argtypes = [u64p, u64p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint64]
     lib.orc_transpose.argtypes = [u64p, u64p, ctypes.c_uint64, ctypes.c_uint64]
+    lib.orc_poseidon_set_constants.argtypes = [u64p, u64p, u64p]
+    lib.orc_poseidon_permute.argtypes = [u64p]
+    lib.orc_hash_no_pad.argtypes = [u64p, ctypes.c_uint64, u64p]
+    lib.orc_two_to_one.argtypes = [u64p, u64p, u64p]
+    lib.orc_merkle.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint, u64p, u64p]
+    lib.orc_fri_fold2.argtypes = [u64p, u64p, ctypes.c_uint, ctypes.c_uint64, u64p]
+    lib.orc_sha256.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_void_p]
+    lib.orc_sha512.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_void_p]
     return lib
+
+
+def poseidon_consts(kind):
+    """(rc, circ, diag) as uint64 arrays: 'small' = the package default (small-integer MDS,
+    fast path), 'big' = random 64-bit MDS entries (generic path)."""
+    import importlib
+    pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    rc, circ, diag = pc.default_constants()
+    rc = np.array(rc, dtype=np.uint64)
+    if kind == "small":
+        return rc, np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64)
+    rng = np.random.default_rng(4242)
+    return rc, rand_field(rng, 12), rand_field(rng, 12)
+
+
+def oracle_merkle(oracle, leaves, cap_h):
+    """leaves [n][leaf_len] -> (digests [*,4], cap [2^cap_h,4]) by the CPU oracle"""
+    a = np.ascontiguousarray(leaves, dtype=np.uint64)
+    n, leaf_len = a.shape
+    log_leaves = n.bit_length() - 1
+    dig = np.zeros(((2 << log_leaves) - (1 << cap_h), 4), dtype=np.uint64)
+    cap = np.zeros((1 << cap_h, 4), dtype=np.uint64)
+    oracle.orc_merkle(ptr(a), leaf_len, log_leaves, cap_h, ptr(dig), ptr(cap))
+    return dig, cap
 
 
 @pytest.fixture(scope="session")
@@ -65,6 +97,14 @@ def emu():
         f.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
     lib.emu_gl_mul_pow2.restype = ctypes.c_uint64
     lib.emu_gl_mul_pow2.argtypes = [ctypes.c_uint64, ctypes.c_int]
+    lib.emu_poseidon_permute.argtypes = [u64p, ctypes.c_uint64, u64p, ctypes.c_int]
+    lib.emu_merkle.argtypes = [u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u64p, u64p,
+                               ctypes.c_int]
+    lib.emu_fri_fold2.argtypes = [u64p, u64p, ctypes.c_uint32, ctypes.c_uint64, u64p]
+    lib.emu_sha256_trace.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p]
+    lib.emu_sha512_trace.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p]
     return lib
 
 

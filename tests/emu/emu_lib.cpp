@@ -89,3 +89,61 @@ extern "C" u64 emu_gl_mul_pow2(u64 x, int s) {
     });
     return found ? r : ~0ull;
 }
+
+// ---- hash kernels under emulation -------------------------------------------------------
+#include "../../0-kno-blobstreamx_amd/csrc/hash_kernels.cuh"
+
+extern "C" int emu_poseidon_permute(u64* states, u64 n, const u64* consts384, int small) {
+    GlpPoseidonConsts k{consts384, consts384 + 360, consts384 + 372};
+    unsigned block = 64, grid = (unsigned)((n + block - 1) / block);
+    if (small) glp_emu_launch(grid, block, 0, [&] { glp_poseidon_permute_kernel<true>(states, n, k); });
+    else glp_emu_launch(grid, block, 0, [&] { glp_poseidon_permute_kernel<false>(states, n, k); });
+    return 0;
+}
+
+extern "C" int emu_merkle(const u64* src, u64 stride, int poly_major, u32 leaf_len, u32 log_leaves, u32 cap_h, u64* digests,
+                          const u64* consts384, int small) {
+    GlpPoseidonConsts k{consts384, consts384 + 360, consts384 + 372};
+    const u64 nl = 1ull << log_leaves;
+    unsigned block = 64, grid = (unsigned)((nl + block - 1) / block);
+    auto leaves = [&](auto sm_, auto pm_) {
+        constexpr bool SM = decltype(sm_)::value != 0, PM = decltype(pm_)::value != 0;
+        glp_emu_launch(grid, block, 0, [&] { glp_hash_leaves_kernel<SM, PM>(src, stride, leaf_len, nl, digests, k); });
+    };
+    if (small) { if (poly_major) leaves(glp_ic<1>{}, glp_ic<1>{}); else leaves(glp_ic<1>{}, glp_ic<0>{}); }
+    else { if (poly_major) leaves(glp_ic<0>{}, glp_ic<1>{}); else leaves(glp_ic<0>{}, glp_ic<0>{}); }
+    u64* prev = digests;
+    u64 cnt = nl;
+    for (u32 lvl = log_leaves; lvl > cap_h; lvl--) {
+        u64* cur = prev + 4 * cnt;
+        cnt >>= 1;
+        unsigned g = (unsigned)((cnt + block - 1) / block);
+        if (small) glp_emu_launch(g, block, 0, [&] { glp_merkle_level_kernel<true>(prev, cur, cnt, k); });
+        else glp_emu_launch(g, block, 0, [&] { glp_merkle_level_kernel<false>(prev, cur, cnt, k); });
+        prev = cur;
+    }
+    return 0;
+}
+
+extern "C" int emu_fri_fold2(const u64* evals, u64* out, u32 log_n, u64 shift, const u64* beta) {
+    std::vector<u64> lo(glp_table_lo_len(log_n)), hi(glp_table_hi_len(log_n) ? glp_table_hi_len(log_n) : 1);
+    glp_fill_table(log_n, 1, lo.data(), hi.data());
+    const u64* hip = glp_table_hi_len(log_n) ? hi.data() : nullptr;
+    const u64 half = 1ull << (log_n - 1);
+    unsigned block = 64, grid = (unsigned)((half + block - 1) / block);
+    u64 half_inv = gl_inv(2), cc = gl_inv(gl_mul(2, shift));
+    gl_ext2 b{beta[0], beta[1]};
+    glp_emu_launch(grid, block, 0, [&] { glp_fri_fold2_kernel<0>(evals, out, log_n, half_inv, cc, b, lo.data(), hip); });
+    return 0;
+}
+
+extern "C" int emu_sha256_trace(const uint8_t* blocks, u64 n_msgs, u32 bpm, u32* digests, u32* trace, const u32* k256) {
+    unsigned block = 64, grid = (unsigned)((n_msgs + block - 1) / block);
+    glp_emu_launch(grid, block, 0, [&] { glp_sha256_trace_kernel<0>(blocks, n_msgs, bpm, digests, trace, k256); });
+    return 0;
+}
+extern "C" int emu_sha512_trace(const uint8_t* blocks, u64 n_msgs, u32 bpm, u64* digests, u64* trace, const u64* k512) {
+    unsigned block = 64, grid = (unsigned)((n_msgs + block - 1) / block);
+    glp_emu_launch(grid, block, 0, [&] { glp_sha512_trace_kernel<0>(blocks, n_msgs, bpm, digests, trace, k512); });
+    return 0;
+}
