@@ -60,6 +60,7 @@ def load_library():
         "glp_set_stream": (ctypes.c_int, [_vp, _vp]),
         "glp_timer_start": (ctypes.c_int, [_vp]),
         "glp_timer_stop": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+        "glp_field_op": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint64]),
         "glp_ntt": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]),
         "glp_ntt_ex": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64,
                                       ctypes.c_uint64, ctypes.c_uint32]),
@@ -188,6 +189,21 @@ class Prover:
         ms = ctypes.c_float()
         self._chk(self.lib.glp_timer_stop(self.ctx, ctypes.byref(ms)), "glp_timer_stop")
         return ms.value
+
+    FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "mul_pow2": 3, "inv": 4}
+
+    def field_op(self, op, a, b=None):
+        """element-wise Goldilocks arithmetic on the GPU (the kernels' own device functions)"""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        da = self.to_device(a)
+        db = self.to_device(np.ascontiguousarray(b, dtype=np.uint64)) if b is not None else None
+        do = self.alloc(max(8, a.nbytes))
+        self._chk(self.lib.glp_field_op(self.ctx, self.FIELD_OPS[op], da.ptr, db.ptr if db else None, do.ptr, a.size), "glp_field_op")
+        out = do.download(a.shape)
+        for x in (da, db, do):
+            if x:
+                x.free()
+        return out
 
     # ---- device-level transforms -------------------------------------------------------
     def ntt_(self, d_io, log_n, batch=1, inverse=False):

@@ -46,46 +46,82 @@ GL_HD u64 gl_sub(u64 a, u64 b) {
 GL_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 GL_HD u64 gl_canon(u64 a) { return a >= GL_P ? a - GL_P : a; }
 
-// (hi*2^64 + lo) mod p, any hi, lo.
+// r (+ 2^64 if carry) mod p, for a sum whose true value is < 2^64 + p
+GL_HD u64 gl_fold_carry(u64 r, bool carry) { return (carry || r >= GL_P) ? r + GL_EPS : r; }
+
+// (hi*2^64 + lo) mod p, any hi, lo:  lo - hi_hi + hi_lo*(2^32 - 1)
 GL_HD u64 gl_reduce128(u64 hi, u64 lo) {
-    u64 hh = hi >> 32, hl = hi & GL_EPS;
-    u64 t0 = lo - hh;
-    if (lo < hh) t0 -= GL_EPS;       // borrow: -2^64 = -(2^32-1)
-    u64 t1 = (hl << 32) - hl;        // hl * (2^32 - 1)
-    u64 r = t0 + t1;
-    if (r < t1) r += GL_EPS;         // carry: +2^64 = +(2^32-1)
-    return gl_canon(r);
+    const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+    u64 t0;
+    const bool bor = __builtin_sub_overflow(lo, (u64)h1, &t0);
+    t0 = bor ? t0 + GL_P : t0;                    // -2^64 = +p - 2^64 ... (mod 2^64): t0 - eps
+    const u64 t1 = ((u64)h0 << 32) - h0;          // h0 * (2^32 - 1)  <= 2^64 - 2^33 + 1
+    u64 r;
+    const bool c = __builtin_add_overflow(t0, t1, &r);
+    return gl_fold_carry(r, c);                   // carry: r + eps < p (r < t1); else one conditional subtract
 }
 
-GL_HD u64 gl_mulhi64(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul64hi(a, b);
-#else
-    return (u64)(((unsigned __int128)a * b) >> 64);
-#endif
+GL_HD u64 gl_mul(u64 a, u64 b) {
+    // 64x64 -> 128 from four 32x32 products chained through v_mad_u64_u32 addends
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p0 = (u64)a0 * b0;
+    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
+    const u64 p2 = (u64)a1 * b0 + (u32)p1;
+    const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    return gl_reduce128(p3, (p2 << 32) | (u32)p0);
 }
-GL_HD u64 gl_mul(u64 a, u64 b) { return gl_reduce128(gl_mulhi64(a, b), a * b); }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 
+// ---- multiplication by powers of two (the twiddles of every radix <= 64 butterfly) ------
+// x * 2^T, 0 < T < 32:  (x << T) + (x >> (64-T)) * (2^32 - 1)
+template <int T>
+GL_HD u64 gl_shl_small(u64 x) {
+    static_assert(T > 0 && T < 32, "");
+    const u64 lo = x << T;
+    const u32 w2 = (u32)(x >> (64 - T));
+    const u64 t1 = ((u64)w2 << 32) - w2;
+    u64 r;
+    const bool c = __builtin_add_overflow(lo, t1, &r);
+    return gl_fold_carry(r, c);
+}
+// x * 2^-K, 0 < K <= 32, branch-free and already canonical (Montgomery-style exact division):
+// m = -x mod 2^K makes x + m*p divisible by 2^K (p = 1 mod 2^32), and
+// (x + m*p) / 2^K = (x + m) / 2^K + (m << (32-K)) * (2^32 - 1)  <  p.
+template <int K>
+GL_HD u64 gl_shr_small(u64 x) {
+    static_assert(K > 0 && K <= 32, "");
+    const u32 m = (K == 32) ? (0u - (u32)x) : ((0u - (u32)x) & ((1u << (K & 31)) - 1u));
+    const u64 a = (x + m) >> (K & 63);
+    const u32 mm = (K == 32) ? m : (m << ((32 - K) & 31));
+    return a + (((u64)mm << 32) - mm);
+}
+// x * 2^32 = -x1 + (x0 + x1) * 2^32  ... as reduce128(hi = x >> 32, lo = x << 32)
+GL_HD u64 gl_shl32(u64 x) { return gl_reduce128(x >> 32, x << 32); }
+
+// |x * 2^S| up to sign, S in [0,192): returns v with  x * 2^S = (gl_pow2_neg(S) ? -v : v).
+// Every case is one or two of the primitives above; exponents 32 < e < 96 go through the
+// inverse shifts using 2^96 = -1  (2^e = -2^-(96-e)).
+constexpr bool gl_pow2_neg(int S) {
+    const int e = S % 96;
+    const bool flip = (e > 32);          // cases routed through -2^-(96-e)
+    return ((S / 96) & 1) != (flip ? 1 : 0);
+}
+template <int S>
+GL_HD u64 gl_mul_pow2_mag(u64 x) {
+    static_assert(S >= 0 && S < 192, "shift out of range");
+    constexpr int e = S % 96;
+    if constexpr (e == 0) return x;
+    else if constexpr (e < 32) return gl_shl_small<e>(x);
+    else if constexpr (e == 32) return gl_shl32(x);
+    else if constexpr (e < 64) return gl_shr_small<32>(gl_shr_small<64 - e>(x));   // 2^-(96-e), 96-e in (32,64)
+    else return gl_shr_small<96 - e>(x);                                           // 96-e in (0,32]
+}
 // x * 2^S mod p for a compile-time S in [0, 192).
 template <int S>
 GL_HD u64 gl_mul_pow2(u64 x) {
-    static_assert(S >= 0 && S < 192, "shift out of range");
-    if constexpr (S == 0) {
-        return x;
-    } else if constexpr (S >= 96) {
-        return gl_neg(gl_mul_pow2<S - 96>(x));  // 2^96 = -1
-    } else if constexpr (S <= 64) {
-        u64 hi = x >> (64 - S);
-        u64 lo = (S == 64) ? 0ULL : (x << (S & 63));
-        return gl_reduce128(hi, lo);
-    } else {
-        // 64 < S < 96: x*2^S = lo'*2^64 + hi'*2^128 with (hi',lo') = x << (S-64);
-        // 2^128 = -2^32, and hi' < 2^32 so hi'<<32 <= p-1 is canonical.
-        u64 lo2 = x << (S - 64);
-        u64 hi2 = x >> (128 - S);
-        return gl_sub(gl_reduce128(lo2, 0), hi2 << 32);
-    }
+    const u64 v = gl_mul_pow2_mag<S>(x);
+    if constexpr (gl_pow2_neg(S)) return gl_neg(v);
+    else return v;
 }
 
 // runtime exponent version (host-side table building, slow paths)

@@ -42,6 +42,31 @@ __global__ void __launch_bounds__(256) glp_lde_prep_kernel(const u64* __restrict
     }
 }
 
+// element-wise field operations (row a1): the same device functions the kernels inline
+__global__ void __launch_bounds__(256) glp_field_op_kernel(int op, const u64* __restrict__ a, const u64* __restrict__ b,
+                                                           u64* __restrict__ out, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 x = a[i], y = b ? b[i] : 0;
+        u64 r = 0;
+        switch (op) {
+            case 0: r = gl_add(x, y); break;
+            case 1: r = gl_sub(x, y); break;
+            case 2: r = gl_mul(x, y); break;
+            case 3: {
+                const int sh = (int)(y % 192);
+                r = x;
+                glp_static_for<0, 192>([&](auto s_) {
+                    constexpr int S = decltype(s_)::value;
+                    if (sh == S) r = gl_mul_pow2<S>(x);
+                });
+                break;
+            }
+            case 4: r = x ? gl_inv(x) : 0; break;
+        }
+        out[i] = r;
+    }
+}
+
 // [rows][cols] -> [cols][rows], 32x32 u64 tiles through LDS (row pad = 1 element)
 __global__ void __launch_bounds__(256) glp_transpose_kernel(const u64* __restrict__ in, u64* __restrict__ out, u64 rows,
                                                             u64 cols, u64 tiles_c) {
@@ -375,6 +400,17 @@ extern "C" int glp_lde_coset(glp_ctx* c, const uint64_t* coeffs, uint64_t* out, 
     GLP_HIPCHK(c, hipGetLastError());
     const u64 N = 1ull << log_N;
     return glp_ntt_impl(c, out, out, log_N, batch, N, N, flags & GLP_NTT_BITREV);
+}
+
+extern "C" int glp_field_op(glp_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n) {
+    if (!c) return GLP_E_INVALID;
+    if (op < 0 || op > 4 || ((!a || !out || (!b && op < 4)) && n)) { glp_set_err(c, "glp_field_op: bad argument"); return GLP_E_INVALID; }
+    if (n == 0) return GLP_OK;
+    u64 blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(glp_field_op_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, op, a, b, out, n);
+    GLP_HIPCHK(c, hipGetLastError());
+    return GLP_OK;
 }
 
 extern "C" int glp_transpose(glp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t rows, uint64_t cols) {

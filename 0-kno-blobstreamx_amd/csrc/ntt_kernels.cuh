@@ -54,8 +54,8 @@ GL_HD void glp_dft_inreg(u64 (&x)[16]) {
             constexpr int e = glp_tw_exp(m, i, INV);
             u64 u = x[i0], v = x[i1];
             x[i0] = gl_add(u, v);
-            if constexpr (e >= 96) x[i1] = gl_mul_pow2<e - 96>(gl_sub(v, u));
-            else x[i1] = gl_mul_pow2<e>(gl_sub(u, v));
+            if constexpr (gl_pow2_neg(e)) x[i1] = gl_mul_pow2_mag<e>(gl_sub(v, u));
+            else x[i1] = gl_mul_pow2_mag<e>(gl_sub(u, v));
         });
     });
 }
@@ -240,21 +240,32 @@ __global__ void __launch_bounds__(1024) glp_ntt_pass_kernel(GlpNttPassArgs a) {
                     lds[base + ((u32)d << lsg) * ldA] = v;
                 });
             } else {
+                // inter-pass twiddle of a STRIP pass: X[k] *= w_N^{j' k}, j' = lo0 + col.  The 16
+                // outputs of this work-item are k = k0 + d*(R/16), so the factors form a geometric
+                // progression: two table look-ups (base, ratio) and a running product instead
+                // of 16 pairs of gathered loads.
+                u64 tw = 1, ratio = 1;
+                if constexpr (MODE == GLP_STRIP) {
+                    const u32 log_N = LOG_R + a.log_m;
+                    const u64 jq = (u64)(lo0 + col);
+                    const u64 e0 = jq * glp_digit_reverse<LOG_R>(row0);      // < N <= 2^32
+                    const u64 e1 = jq << (LOG_R - q);                        // j' * R/r
+                    if (log_N <= 12) {
+                        tw = a.tw_lo[e0];
+                        ratio = a.tw_lo[e1];
+                    } else {
+                        tw = gl_mul(a.tw_lo[e0 & 4095u], a.tw_hi[e0 >> 12]);
+                        ratio = gl_mul(a.tw_lo[e1 & 4095u], a.tw_hi[e1 >> 12]);
+                    }
+                }
                 glp_static_for<0, (int)r>([&](auto d_) {
                     constexpr int d = decltype(d_)::value;
                     u64 v = x[g * r + glp_bitrev_c(d, q)];
                     const u32 pos = row0 + (u32)d;                  // sigma == 1 in the last step
                     const u32 k = glp_digit_reverse<LOG_R>(pos);    // natural output index in [0,R)
                     if constexpr (MODE == GLP_STRIP) {
-                        const u32 log_N = LOG_R + a.log_m;
-                        const u64 e = (u64)(lo0 + col) * k;         // < N <= 2^32
-                        if (log_N <= 12) {
-                            v = gl_mul(v, a.tw_lo[e]);
-                        } else {
-                            u64 w = gl_mul(a.tw_lo[e & 4095u], a.tw_hi[e >> 12]);
-                            v = gl_mul(v, w);
-                        }
-                        if (a.scale != 1) v = gl_mul(v, a.scale);
+                        v = gl_mul(v, tw);
+                        if constexpr (d + 1 < (int)r) tw = gl_mul(tw, ratio);
                         const u32 orow = a.rev ? glp_bitrev32(k, LOG_R) : k;
                         a.dst[dbase + ((u64)orow << a.log_m) + col] = v;
                     } else if constexpr (MODE == GLP_FINAL_T) {

@@ -57,6 +57,13 @@ int glp_set_stream(glp_ctx* ctx, void* hip_stream);
 int glp_timer_start(glp_ctx* ctx);
 int glp_timer_stop(glp_ctx* ctx, float* ms);
 
+/* ---- field arithmetic (upstream name recalled: GoldilocksField) ------
+ * element-wise on device arrays of n canonical elements: out[i] = a[i] (op) b[i].
+ * op: 0 add, 1 sub, 2 mul, 3 a[i] * 2^(b[i] mod 192), 4 inverse of a[i] (0 -> 0).
+ * The prover never calls this; it exposes the exact device arithmetic of the kernels to
+ * parity tests and to hosts that need a few field operations on resident data. */
+int glp_field_op(glp_ctx* ctx, int op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n);
+
 /* ---- NTT / LDE (upstream names recalled: plonky2_field::fft::
  *      fft / ifft / coset_fft, PolynomialCoeffs::lde, fri::oracle::PolynomialBatch) ------ */
 /* in place, natural order in and out:  X[k] = sum_j x[j] w_n^{jk},  w_n = 7^((p-1)/n) */
