@@ -68,7 +68,7 @@ def load_library():
                                          ctypes.c_uint64, ctypes.c_uint32]),
         "glp_transpose": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64]),
         "glp_ntt_set_plan": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_char_p]),
-        "glp_ntt_describe_plan": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p,
+        "glp_ntt_describe_plan": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p,
                                                  ctypes.c_size_t]),
         "glp_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
         "glp_last_pass_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
@@ -224,9 +224,9 @@ class Prover:
     def set_plan(self, log_n, plan):
         self._chk(self.lib.glp_ntt_set_plan(self.ctx, log_n, plan.encode() if plan else None), "glp_ntt_set_plan")
 
-    def describe_plan(self, log_n, flags=0):
+    def describe_plan(self, log_n, batch=1, flags=0):
         buf = ctypes.create_string_buffer(256)
-        self._chk(self.lib.glp_ntt_describe_plan(self.ctx, log_n, flags, buf, 256), "glp_ntt_describe_plan")
+        self._chk(self.lib.glp_ntt_describe_plan(self.ctx, log_n, batch, flags, buf, 256), "glp_ntt_describe_plan")
         return buf.value.decode()
 
     def set_profiling(self, on):

@@ -279,11 +279,11 @@ static const char* plan_override_for(glp_ctx* c, uint32_t log_n) {
     return env;
 }
 
-extern "C" int glp_ntt_describe_plan(glp_ctx* c, uint32_t log_n, uint32_t flags, char* buf, size_t len) {
+extern "C" int glp_ntt_describe_plan(glp_ctx* c, uint32_t log_n, uint32_t batch, uint32_t flags, char* buf, size_t len) {
     if (!c || !buf || len == 0) return GLP_E_INVALID;
     if (log_n < GLP_MIN_LOG_R) { snprintf(buf, len, "small(n=%u)", 1u << log_n); return GLP_OK; }
     GlpPlan pl;
-    if (glp_make_plan((int)log_n, (flags & GLP_NTT_BITREV) ? 1 : 0, 1, plan_override_for(c, log_n), &pl) != 0) return GLP_E_UNSUPPORTED;
+    if (glp_make_plan((int)log_n, (flags & GLP_NTT_BITREV) ? 1 : 0, 1, plan_override_for(c, log_n), &pl, batch ? batch : 1) != 0) return GLP_E_UNSUPPORTED;
     size_t off = 0;
     static const char* mn[] = {"strip", "finalT", "finalRows"};
     for (int i = 0; i < pl.npass && off < len; i++)
@@ -327,7 +327,7 @@ int glp_ntt_impl(glp_ctx* c, const uint64_t* src, uint64_t* dst, uint32_t log_n,
     GlpPlan pl;
     memset(&pl, 0, sizeof(pl));
     if (log_n >= GLP_MIN_LOG_R) {
-        if (glp_make_plan((int)log_n, rev, src == dst, plan_override_for(c, log_n), &pl) != 0) {
+        if (glp_make_plan((int)log_n, rev, src == dst, plan_override_for(c, log_n), &pl, batch) != 0) {
             glp_set_err(c, "glp_ntt: no plan for log_n=%u", log_n);
             return GLP_E_UNSUPPORTED;
         }

@@ -73,6 +73,11 @@ int glp_exec_ntt(Backend& be, const GlpPlan* pl, const GlpNttCall& c) {
         }
         unsigned long long grid = glp_pass_grid(&ps, c.log_n, c.batch);
         if (grid == 0 || grid > 0x7fffffffull) return -4;
+        a.xcd_group_log = 0;
+        if (ps.mode == GLP_STRIP && ps.log_c < 4 && ps.log_m >= 4) {
+            const u32 g = 4u - (u32)ps.log_c;
+            if (grid % (8ull << g) == 0) a.xcd_group_log = g;
+        }
         int rc = be.launch_pass(ps, c.inverse, grid, glp_pass_threads(&ps), glp_pass_lds_bytes(&ps), a);
         if (rc) return rc;
     }

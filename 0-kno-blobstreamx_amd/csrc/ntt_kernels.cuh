@@ -77,6 +77,7 @@ struct GlpNttPassArgs {
     u32 rev;               // bit-reversed output order (STRIP: row placement; FINAL_ROWS: index)
     u32 nprev;             // FINAL_T: number of earlier passes, and their log2 radices
     u32 log_rprev[3];
+    u32 xcd_group_log;     // STRIP with C*8 < 128 B: log2 of strips sharing one 128-B line (0 = no remap)
 };
 
 template <int LOG_R>
@@ -128,7 +129,21 @@ __global__ void __launch_bounds__(1024) glp_ntt_pass_kernel(GlpNttPassArgs a) {
     const u32 NT = (R << log_c) >> 4;        // == blockDim.x (checked on the host)
     const u32 tid = threadIdx.x;
     const u32 ldA = C + 1;                   // layout A: [row][C+1]
-    const u64 tile = blockIdx.x;
+    u64 tile = blockIdx.x;
+    if constexpr (MODE == GLP_STRIP) {
+        // Strips narrower than a 128-B line share lines with their neighbours.  Workgroups b and
+        // b+8 are observed to land on the same XCD (private L2), so give the 2^g line-sharing
+        // strips the ids b, b+8, ...: the second toucher then hits in L2 instead of HBM.
+        // Bijective on [0, grid) because the host only enables it when grid % (8 << g) == 0;
+        // placement affects speed only, never results.
+        const u32 g = a.xcd_group_log;
+        if (g) {
+            const u64 per = 8ull << g;
+            const u64 base = tile & ~(per - 1);
+            const u32 rem = (u32)(tile & (per - 1));
+            tile = base + ((u64)(rem & 7u) << g) + (rem >> 3);
+        }
+    }
 
     // ---- tile geometry -------------------------------------------------------------
     // STRIP: tile -> (poly, hi, lo0); element (row, col) at  hi*R*m + row*m + lo0 + col

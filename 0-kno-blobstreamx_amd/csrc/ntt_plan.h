@@ -33,7 +33,8 @@ struct GlpPlan {
     int needs_scratch;
 };
 
-// default columns-per-tile: tiles of 2^12 elements (32 KiB) up to R = 2^8 ... see DESIGN.md
+// default columns-per-tile (measured, profiles/r01_ntt_*_plan_sweep.jsonl): tiles of 2^12
+// elements (32 KiB of LDS, 4-5 workgroups per CU) up to R = 2^8, 2^13 up to R = 2^10, then 2^14
 static inline int glp_default_log_c(int log_r) {
     int tile_log = log_r <= 8 ? 12 : (log_r <= 10 ? 13 : 14);
     return tile_log - log_r;
@@ -57,7 +58,7 @@ static inline int glp_parse_plan(const char* s, int* lr, int* lc) {
 
 // Build the plan.  `ovr` optionally forces the radices ("12:2,12:2").  Returns 0 on success.
 // in_place: src == dst.
-static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ovr, GlpPlan* pl) {
+static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ovr, GlpPlan* pl, unsigned long long batch = 1) {
     memset(pl, 0, sizeof(*pl));
     pl->log_n = log_n;
     pl->rev = rev;
@@ -91,6 +92,11 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
         ps->mode = last ? ((rev || np == 1) ? GLP_FINAL_ROWS : GLP_FINAL_T) : GLP_STRIP;
         ps->log_m = last ? 0 : rem;
         int c = lc[i] >= 0 ? lc[i] : glp_default_log_c(lr[i]);
+        if (lc[i] < 0) {
+            // small batches: prefer more, narrower tiles until the launch fills the chip
+            // (>= 2 workgroups per CU), but never narrower than 32-byte segments
+            while (c > 2 && c + lr[i] > 10 && ((batch << log_n) >> (lr[i] + c)) < 512) c--;
+        }
         if (c + lr[i] < 10) c = 10 - lr[i];                 // at least one wavefront of threads
         if (c + lr[i] > 14) c = 14 - lr[i];                 // at most 1024 threads
         if (!last && c > rem) c = rem;                      // strip no wider than the axis stride

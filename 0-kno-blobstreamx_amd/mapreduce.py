@@ -1,0 +1,70 @@
+"""MapReduce over header batches across GPUs (upstream name
+recalled: plonky2x ``mapreduce`` generator — reference file:line NONE, the mount is empty).
+
+Map: leaf i of a skip/data-commitment circuit is proved on rank ``i % world`` (one process
+per GPU, independent leaves, no data-path collective while proving).  Exchange: ONE all-gather
+of the fixed-size, zero-padded leaf-proof blobs over RCCL/xGMI (``torch.distributed``
+backend "nccl" on GPUs, "gloo" in the CPU tests).  Reduce: every rank (or rank 0) then holds
+all leaf proofs in leaf order for the recursive aggregation.
+
+Payloads are O(100 KiB) per leaf: the all-gather is latency-bound, so it is issued once per
+MapReduce level with all of a rank's leaves packed into one tensor, not once per leaf.
+"""
+import struct
+
+import torch
+import torch.distributed as dist
+
+HEADER = struct.Struct("<QQ")  # (leaf index, payload length)
+
+
+def leaves_of_rank(n_leaves, rank, world):
+    """leaf i -> rank i % world (round-robin keeps ranks within one leaf of each other)"""
+    return list(range(rank, n_leaves, world))
+
+
+def pack_leaves(blobs, padded_len):
+    """[(leaf_index, bytes)] -> uint8 tensor [n_local, HEADER + padded_len] (zero padded)"""
+    rec = HEADER.size + padded_len
+    out = torch.zeros((len(blobs), rec), dtype=torch.uint8)
+    for r, (idx, b) in enumerate(blobs):
+        if len(b) > padded_len:
+            raise ValueError(f"leaf {idx}: proof of {len(b)} bytes exceeds padded_len {padded_len}")
+        row = HEADER.pack(idx, len(b)) + b
+        out[r, : len(row)] = torch.frombuffer(bytearray(row), dtype=torch.uint8)
+    return out
+
+
+def allgather_leaf_proofs(local_blobs, n_leaves, padded_len, device=None):
+    """Every rank passes its own [(leaf_index, proof_bytes)]; returns the list of all
+    ``n_leaves`` proofs in leaf order on every rank.  Ranks may own different leaf counts
+    (n_leaves % world != 0): shorter ranks pad with empty records."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    per_rank = (n_leaves + world - 1) // world
+    mine = pack_leaves(local_blobs, padded_len)
+    rec = mine.shape[1] if mine.numel() else HEADER.size + padded_len
+    buf = torch.zeros((per_rank, rec), dtype=torch.uint8)
+    # empty slots carry leaf index = 2^64-1 so they can be told from leaf 0
+    empty = torch.frombuffer(bytearray(HEADER.pack(2**64 - 1, 0)), dtype=torch.uint8)
+    buf[:, : HEADER.size] = empty
+    buf[: mine.shape[0]] = mine
+    if device is not None:
+        buf = buf.to(device)
+    if world > 1:
+        out = torch.empty((world * per_rank, rec), dtype=torch.uint8, device=buf.device)
+        dist.all_gather_into_tensor(out, buf)
+    else:
+        out = buf
+    out = out.cpu()
+    proofs = [None] * n_leaves
+    for row in out:
+        idx, ln = HEADER.unpack(bytes(row[: HEADER.size].tolist()))
+        if idx == 2**64 - 1:
+            continue
+        if idx >= n_leaves or proofs[idx] is not None:
+            raise ValueError(f"bad or duplicate leaf index {idx}")
+        proofs[idx] = bytes(row[HEADER.size: HEADER.size + ln].tolist())
+    missing = [i for i, p in enumerate(proofs) if p is None]
+    if missing:
+        raise ValueError(f"leaf proofs missing after all-gather: {missing[:8]}")
+    return proofs

@@ -29,6 +29,27 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by profiles/summarize_pmc.py --traffic
+
+
+def pmc_traffic_bytes(plan_desc, elements):
+    """HBM bytes per transform from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    per launch, scaled by element count), or None when a pass of this plan was not profiled."""
+    import re
+    try:
+        with open(PMC_TRAFFIC) as f:
+            t = json.load(f)["kernels"]
+    except OSError:
+        return None
+    mode_id = {"strip": 0, "finalT": 1, "finalRows": 2}
+    total = 0.0
+    for mode, lr, lc in re.findall(r"(strip|finalT|finalRows)\(R=2\^(\d+),C=2\^(\d+)\)", plan_desc):
+        key = f"void glp_ntt_pass_kernel<{lr}, {mode_id[mode]}, false>(GlpNttPassArgs)"
+        ent = t.get(key)
+        if not ent or ent.get("log_c") not in (None, int(lc)):
+            return None
+        total += (ent["fetch_bytes"] + ent["write_bytes"]) * elements / float(1 << 27)
+    return total or None
 
 
 def splitmix_fill(n_elems, seed):
@@ -58,22 +79,23 @@ def cpu_baseline(log_n, seconds_target=15.0):
     built here) on a bounded sample: `polys` transforms of size 2^log_n, OpenMP over the batch."""
     orc = graft.load_oracle()
     u64p = ctypes.POINTER(ctypes.c_uint64)
-    orc.orc_ntt.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint64, ctypes.c_int]
+    orc.orc_ntt_fast.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint64, ctypes.c_int]
     orc.orc_num_threads.restype = ctypes.c_int
     cores = orc.orc_num_threads()
     n = 1 << log_n
     probe = splitmix_fill(n * cores, 1).reshape(cores, n)
     t = time.perf_counter()
-    orc.orc_ntt(probe.ctypes.data_as(u64p), log_n, cores, 0)
+    orc.orc_ntt_fast(probe.ctypes.data_as(u64p), log_n, cores, 0)
     dt = time.perf_counter() - t
     rounds = max(1, min(64, int(seconds_target / max(dt, 1e-3))))
     polys = cores * rounds
     x = splitmix_fill(n * polys, 2).reshape(polys, n)
     t = time.perf_counter()
-    orc.orc_ntt(x.ctypes.data_as(u64p), log_n, polys, 0)
+    orc.orc_ntt_fast(x.ctypes.data_as(u64p), log_n, polys, 0)
     dt = time.perf_counter() - t
     return {"value": round(16.0 * n * polys / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": f"{polys} forward NTTs of 2^{log_n} (16*n bytes each), OpenMP over the batch, {dt:.1f} s"}
+            "sample": f"{polys} forward NTTs of 2^{log_n} (16*n bytes each) by oracle/gl_fast.c (hand-reduced radix-2, "
+                      f"gcc -O3 -march=native), OpenMP over the batch, {dt:.1f} s"}
 
 
 SWEEP = {
@@ -108,7 +130,7 @@ def sweep():
                 pm = pr.last_pass_ms()
                 acc = pm if acc is None else [a + b for a, b in zip(acc, pm)]
             pr.set_profiling(False)
-            print(json.dumps({"log_n": log_n, "batch": batch, "plan": pr.describe_plan(log_n), "ms": round(ms, 4),
+            print(json.dumps({"log_n": log_n, "batch": batch, "plan": pr.describe_plan(log_n, batch), "ms": round(ms, 4),
                               "gbps": round(16.0 * n * batch / ms / 1e6, 1), "pass_ms": [round(a / 5, 4) for a in acc]}),
                   flush=True)
         pr.set_plan(log_n, None)
@@ -241,10 +263,11 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"forward NTT, n=2^{log_n}, batch={batch} per GPU, in place, natural order "
                                    f"(BASELINE configs[1] wires shape)", "log_n": log_n, "batch_per_gpu": batch,
-                       "plan": pr.describe_plan(log_n), "algorithmic_bytes_per_step": alg_bytes,
+                       "plan": pr.describe_plan(log_n, batch), "algorithmic_bytes_per_step": alg_bytes,
                        "event_ms_per_step": round(ev_ms / args.steps, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": pmc_traffic_bytes(pr.describe_plan(log_n, batch), float(n) * batch),
                          "kernel": "glp_ntt_pass_kernel (all passes of one transform)",
                          "pass_ms": [round(m, 4) for m in pass_ms],
                          "pass_gbps": [round(alg_bytes / (m * 1e-3) / 1e9, 1) for m in pass_ms]},
@@ -259,7 +282,7 @@ def main():
             ms = time_ntt(pr, dd, ln, b, steps=10, warmup=3)
             dd.free()
             sizes[f"2^{ln}xb{b}"] = {"ms": round(ms, 4), "gbps": round(16.0 * (1 << ln) * b / (ms * 1e-3) / 1e9, 1),
-                                     "plan": pr.describe_plan(ln)}
+                                     "plan": pr.describe_plan(ln, b)}
         out["sizes"] = sizes
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(log_n)

@@ -80,8 +80,8 @@ int glp_transpose(glp_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint64_t 
 /* force the pass structure of subsequent NTTs of size 2^log_n ("r:c,r:c,..." log2 radix :
  * log2 columns per pass; NULL/"" = default heuristic).  Tuning/benchmark aid. */
 int glp_ntt_set_plan(glp_ctx* ctx, uint32_t log_n, const char* plan);
-/* describe the plan that would be used (for logs): writes a NUL-terminated string */
-int glp_ntt_describe_plan(glp_ctx* ctx, uint32_t log_n, uint32_t flags, char* buf, size_t buf_len);
+/* describe the plan that would be used for this size and batch (for logs): NUL-terminated */
+int glp_ntt_describe_plan(glp_ctx* ctx, uint32_t log_n, uint32_t batch, uint32_t flags, char* buf, size_t buf_len);
 /* per-pass kernel times (ms) of the LAST glp_ntt*_ call when profiling is on; n_out <= 4 */
 int glp_set_profiling(glp_ctx* ctx, int on);
 int glp_last_pass_ms(glp_ctx* ctx, float* ms, int* n_out);

@@ -41,6 +41,7 @@ def oracle():
     lib.orc_dft_naive.argtypes = [u64p, u64p, ctypes.c_uint, ctypes.c_int]
     lib.orc_ntt.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint64, ctypes.c_int]
     lib.orc_ntt_par.argtypes = [u64p, ctypes.c_uint, ctypes.c_int]
+    lib.orc_ntt_fast.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint64, ctypes.c_int]
     lib.orc_bitrev_rows.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint64]
     lib.orc_lde_coset.argtypes = [u64p, u64p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint64]
     lib.orc_transpose.argtypes = [u64p, u64p, ctypes.c_uint64, ctypes.c_uint64]

@@ -66,7 +66,7 @@ extern "C" int emu_ntt(const u64* src, u64* dst, u64 src_stride, u64 dst_stride,
     EmuBackend be;
     GlpPlan pl;
     if (log_n >= GLP_MIN_LOG_R) {
-        int rc = glp_make_plan(log_n, rev, src == dst, plan_override, &pl);
+        int rc = glp_make_plan(log_n, rev, src == dst, plan_override, &pl, batch);
         if (rc) return rc;
     }
     std::vector<u64> scratch;

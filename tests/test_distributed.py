@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: two processes over gloo.  Covers the MapReduce leaf sharding and the
+all-gather of padded leaf proofs (row a11), and bench.py's rank/time reduction arithmetic."""
+import hashlib
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def fake_proof(i):
+    """deterministic stand-in payload of leaf-dependent length"""
+    return hashlib.sha256(b"leaf%d" % i).digest() * (1 + i % 5) + bytes([i % 256])
+
+
+def _worker(rank, world, port, n_leaves, q):
+    import importlib
+    import __graft_entry__ as graft
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mr = importlib.import_module(graft.PKG_NAME + ".mapreduce")
+    mine = mr.leaves_of_rank(n_leaves, rank, world)
+    local = [(i, fake_proof(i)) for i in mine]
+    proofs = mr.allgather_leaf_proofs(local, n_leaves, padded_len=200)
+    ok = proofs == [fake_proof(i) for i in range(n_leaves)]
+    # the bench's max-over-ranks time reduction
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, ok, mine, float(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n_leaves", [8, 7, 1])
+def test_mapreduce_allgather_two_ranks(n_leaves):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_leaves, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    owned = []
+    for rank, ok, mine, tmax in res:
+        assert ok, f"rank {rank} did not reassemble the leaf proofs"
+        assert tmax == 2.0
+        owned += mine
+    assert sorted(owned) == list(range(n_leaves))
+
+
+def test_single_process_gather_and_errors():
+    import importlib
+    import __graft_entry__ as graft
+    mr = importlib.import_module(graft.PKG_NAME + ".mapreduce")
+    blobs = [(i, fake_proof(i)) for i in range(5)]
+    assert mr.allgather_leaf_proofs(blobs, 5, 200) == [b for _, b in blobs]
+    with pytest.raises(ValueError):
+        mr.pack_leaves([(0, b"x" * 300)], 200)
+    with pytest.raises(ValueError):
+        mr.allgather_leaf_proofs(blobs[:4], 5, 200)       # a leaf is missing

@@ -39,6 +39,7 @@ CASES = [
     (13, 1, 0, 0, None, True), (14, 2, 1, 0, None, False), (15, 1, 0, 1, None, True), (16, 2, 1, 1, None, True),
     (16, 1, 0, 0, "8:4,8:4", True), (16, 1, 0, 0, "10:2,6:4", False), (18, 1, 0, 0, "6:4,6:4,6:4", True),
     (18, 1, 1, 0, "6:4,6:4,6:4", False), (18, 1, 0, 1, "6:4,6:4,6:4", True), (17, 1, 0, 0, "6:3,11:3", True),
+    (18, 1, 0, 0, "10:3,8:4", True), (18, 2, 1, 0, "10:2,8:4", False),
 ]
 
 

@@ -41,6 +41,7 @@ def test_ntt_matches_golden_and_naive(oracle):
         x = np.array([int(v) for v in c["x"]], dtype=np.uint64)
         fwd = np.array([int(v) for v in c["fwd"]], dtype=np.uint64)
         inv = np.array([int(v) for v in c["inv"]], dtype=np.uint64)
+        want_inv = inv
         a = x.copy()
         oracle.orc_ntt(ptr(a), log_n, 1, 0)
         assert np.array_equal(a, fwd)
@@ -50,6 +51,10 @@ def test_ntt_matches_golden_and_naive(oracle):
         a = x.copy()
         oracle.orc_ntt_par(ptr(a), log_n, 0)
         assert np.array_equal(a, fwd)
+        for inv, want in ((0, fwd), (1, want_inv)):          # the cpu_baseline leg (gl_fast.c)
+            a = x.copy()
+            oracle.orc_ntt_fast(ptr(a), log_n, 1, inv)
+            assert np.array_equal(a, want)
         if log_n <= 8:
             out = np.zeros_like(x)
             oracle.orc_dft_naive(ptr(x.copy()), ptr(out), log_n, 0)
@@ -103,3 +108,13 @@ def test_tendermint_merkle(oracle):
         o = ctypes.create_string_buffer(32)
         oracle.orc_tm_merkle_root(leaves, t["leaf_len"], c["n"], o)
         assert o.raw.hex() == c["root"]
+
+
+def test_fast_baseline_matches_naive_oracle_at_2_16(oracle):
+    from conftest import rand_field
+    rng = np.random.default_rng(16)
+    x = rand_field(rng, (3, 1 << 16))
+    a, b = x.copy(), x.copy()
+    oracle.orc_ntt(ptr(a), 16, 3, 0)
+    oracle.orc_ntt_fast(ptr(b), 16, 3, 0)
+    assert np.array_equal(a, b)
