@@ -34,10 +34,15 @@ GL_HD void glp_static_for(F&& f) {
     }
 }
 
+// Cost model on gfx950 (profiles/r01_ubench_valu2.txt): plain 32-bit VOP2 ops issue in ~2.3
+// cycles per wave64; everything 64-bit, VOP3, carry- or mask-producing (v_lshl_add_u64,
+// v_mad_u64_u32, v_cmp_*, v_cndmask, v_add_co/v_addc) in ~4.2.  Hence "+ (cond ? eps : 0)"
+// (one v_cndmask + one 64-bit add) rather than computing both candidates and selecting
+// (one more 64-bit add and a second v_cndmask).
 GL_HD u64 gl_add(u64 a, u64 b) {
-    u64 s = a + b;
-    u64 t = s + GL_EPS;  // s - p (mod 2^64)
-    return (s < a || s >= GL_P) ? t : s;
+    const u64 s = a + b;
+    const bool over = (s < a) | (s >= GL_P);     // true sum >= p
+    return s + (over ? GL_EPS : 0ULL);            // - p  (mod 2^64)
 }
 GL_HD u64 gl_sub(u64 a, u64 b) {
     u64 d = a - b;
@@ -47,7 +52,7 @@ GL_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 GL_HD u64 gl_canon(u64 a) { return a >= GL_P ? a - GL_P : a; }
 
 // r (+ 2^64 if carry) mod p, for a sum whose true value is < 2^64 + p
-GL_HD u64 gl_fold_carry(u64 r, bool carry) { return (carry || r >= GL_P) ? r + GL_EPS : r; }
+GL_HD u64 gl_fold_carry(u64 r, bool carry) { return r + ((carry | (r >= GL_P)) ? GL_EPS : 0ULL); }
 
 // (hi*2^64 + lo) mod p, any hi, lo:  lo - hi_hi + hi_lo*(2^32 - 1)
 GL_HD u64 gl_reduce128(u64 hi, u64 lo) {

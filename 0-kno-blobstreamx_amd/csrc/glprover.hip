@@ -132,7 +132,7 @@ struct HipBackend {
         if (rc != GLP_OK) return rc;
         if (lds > 160 * 1024 || block > 1024 || block < 64) { glp_set_err(c, "bad launch geometry"); return GLP_E_INVALID; }
         mark(2 * npass);
-        hipError_t e = glp_launch_ntt_pass(ps.log_r, ps.mode, inv, (unsigned)grid, block, lds, c->stream, &a);
+        hipError_t e = glp_launch_ntt_pass(ps.log_r, ps.mode, inv, ps.log_e, (unsigned)grid, block, lds, c->stream, &a);
         mark(2 * npass + 1);
         npass++;
         if (e != hipSuccess) { glp_set_err(c, "ntt pass launch: %s", hipGetErrorString(e)); return GLP_E_HIP; }
@@ -259,7 +259,7 @@ extern "C" int glp_ntt_set_plan(glp_ctx* c, uint32_t log_n, const char* plan) {
         GlpPlan pl;
         if (log_n < GLP_MIN_LOG_R) return GLP_E_INVALID;
         int lr[GLP_MAX_PASSES], lc[GLP_MAX_PASSES];
-        int np = glp_parse_plan(plan, lr, lc), sum = 0;
+        int np = glp_parse_plan(plan, lr, lc, nullptr), sum = 0;
         for (int i = 0; i < np; i++) sum += lr[i];
         if (np == 0 || sum != (int)log_n || glp_make_plan((int)log_n, 0, 1, plan, &pl) != 0) {
             glp_set_err(c, "plan '%s' does not fit log_n=%u", plan, log_n);
@@ -287,7 +287,8 @@ extern "C" int glp_ntt_describe_plan(glp_ctx* c, uint32_t log_n, uint32_t batch,
     size_t off = 0;
     static const char* mn[] = {"strip", "finalT", "finalRows"};
     for (int i = 0; i < pl.npass && off < len; i++)
-        off += (size_t)snprintf(buf + off, len - off, "%s%s(R=2^%d,C=2^%d)", i ? "+" : "", mn[pl.p[i].mode], pl.p[i].log_r, pl.p[i].log_c);
+        off += (size_t)snprintf(buf + off, len - off, "%s%s(R=2^%d,C=2^%d%s)", i ? "+" : "", mn[pl.p[i].mode], pl.p[i].log_r, pl.p[i].log_c,
+                                pl.p[i].log_e == 5 ? ",E=32" : "");
     return GLP_OK;
 }
 

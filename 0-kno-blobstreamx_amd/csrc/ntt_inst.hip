@@ -8,9 +8,9 @@
 #error "compile with -DGLP_INST_LOG_R=<6..12>"
 #endif
 
-template <int MODE, bool INV>
+template <int MODE, bool INV, int LOG_E>
 static hipError_t launch_one(unsigned grid, unsigned block, size_t lds, hipStream_t st, const GlpNttPassArgs& a) {
-    auto kern = glp_ntt_pass_kernel<GLP_INST_LOG_R, MODE, INV>;
+    auto kern = glp_ntt_pass_kernel<GLP_INST_LOG_R, MODE, INV, LOG_E>;
     static bool attr_done = false;   // one ctx per process per GPU: no concurrent first call
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -23,15 +23,24 @@ static hipError_t launch_one(unsigned grid, unsigned block, size_t lds, hipStrea
 
 #define GLP_CAT2(a, b) a##b
 #define GLP_CAT(a, b) GLP_CAT2(a, b)
-extern "C" hipError_t GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R)(int mode, int inv, unsigned grid, unsigned block,
-                                                                   size_t lds, hipStream_t st, const GlpNttPassArgs* a) {
+template <int LOG_E>
+static hipError_t launch_mode(int mode, int inv, unsigned grid, unsigned block, size_t lds, hipStream_t st, const GlpNttPassArgs* a) {
     switch (mode * 2 + (inv ? 1 : 0)) {
-        case GLP_STRIP * 2 + 0: return launch_one<GLP_STRIP, false>(grid, block, lds, st, *a);
-        case GLP_STRIP * 2 + 1: return launch_one<GLP_STRIP, true>(grid, block, lds, st, *a);
-        case GLP_FINAL_T * 2 + 0: return launch_one<GLP_FINAL_T, false>(grid, block, lds, st, *a);
-        case GLP_FINAL_T * 2 + 1: return launch_one<GLP_FINAL_T, true>(grid, block, lds, st, *a);
-        case GLP_FINAL_ROWS * 2 + 0: return launch_one<GLP_FINAL_ROWS, false>(grid, block, lds, st, *a);
-        case GLP_FINAL_ROWS * 2 + 1: return launch_one<GLP_FINAL_ROWS, true>(grid, block, lds, st, *a);
+        case GLP_STRIP * 2 + 0: return launch_one<GLP_STRIP, false, LOG_E>(grid, block, lds, st, *a);
+        case GLP_STRIP * 2 + 1: return launch_one<GLP_STRIP, true, LOG_E>(grid, block, lds, st, *a);
+        case GLP_FINAL_T * 2 + 0: return launch_one<GLP_FINAL_T, false, LOG_E>(grid, block, lds, st, *a);
+        case GLP_FINAL_T * 2 + 1: return launch_one<GLP_FINAL_T, true, LOG_E>(grid, block, lds, st, *a);
+        case GLP_FINAL_ROWS * 2 + 0: return launch_one<GLP_FINAL_ROWS, false, LOG_E>(grid, block, lds, st, *a);
+        case GLP_FINAL_ROWS * 2 + 1: return launch_one<GLP_FINAL_ROWS, true, LOG_E>(grid, block, lds, st, *a);
     }
+    return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R)(int mode, int inv, int log_e, unsigned grid, unsigned block,
+                                                                   size_t lds, hipStream_t st, const GlpNttPassArgs* a) {
+    if (log_e == 4) return launch_mode<4>(mode, inv, grid, block, lds, st, a);
+#if GLP_INST_LOG_R == 9 || GLP_INST_LOG_R == 10
+    if (log_e == 5) return launch_mode<5>(mode, inv, grid, block, lds, st, a);
+#endif
     return hipErrorInvalidValue;
 }

@@ -41,8 +41,8 @@ constexpr int glp_tw_exp(int m, int i, bool inv) {
 }
 
 // In-register DIF DFT of size 2^Q on x[OFF .. OFF+2^Q); X[k] lands in x[OFF + bitrev_Q(k)].
-template <int Q, bool INV, int OFF>
-GL_HD void glp_dft_inreg(u64 (&x)[16]) {
+template <int Q, bool INV, int OFF, int NX>
+GL_HD void glp_dft_inreg(u64 (&x)[NX]) {
     glp_static_for<0, Q>([&](auto s_) {
         constexpr int s = decltype(s_)::value;
         constexpr int half = 1 << (Q - 1 - s);
@@ -80,18 +80,19 @@ struct GlpNttPassArgs {
     u32 xcd_group_log;     // STRIP with C*8 < 128 B: log2 of strips sharing one 128-B line (0 = no remap)
 };
 
-template <int LOG_R>
+// LOG_E = log2 of the elements held per work-item (4: radix <= 16 steps, 5: radix <= 32 steps)
+template <int LOG_R, int LOG_E>
 struct GlpSteps {
-    static constexpr int S = (LOG_R + 3) / 4;                       // register steps
-    static constexpr int q(int t) { return t == 0 ? LOG_R - 4 * (S - 1) : 4; }  // small radix first
-    static constexpr int log_sigma(int t) { return 4 * (S - 1 - t); }           // stride of digit t
-    static constexpr int low_bits(int t) { return t == 0 ? 0 : q(0) + 4 * (t - 1); }
+    static constexpr int S = (LOG_R + LOG_E - 1) / LOG_E;                       // register steps
+    static constexpr int q(int t) { return t == 0 ? LOG_R - LOG_E * (S - 1) : LOG_E; }  // small radix first
+    static constexpr int log_sigma(int t) { return LOG_E * (S - 1 - t); }           // stride of digit t
+    static constexpr int low_bits(int t) { return t == 0 ? 0 : q(0) + LOG_E * (t - 1); }
 };
 
 // natural index k of the value sitting at tile row `pos` after all steps (digit reversal)
-template <int LOG_R>
+template <int LOG_R, int LOG_E>
 GL_HD u32 glp_digit_reverse(u32 pos) {
-    using ST = GlpSteps<LOG_R>;
+    using ST = GlpSteps<LOG_R, LOG_E>;
     u32 k = 0;
     glp_static_for<0, ST::S>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
@@ -118,15 +119,16 @@ GL_HD u32 glp_bitrev32(u32 v, u32 bits) {
 #define GLP_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) u64 name[]
 #endif
 
-template <int LOG_R, int MODE, bool INV>
-__global__ void __launch_bounds__(1024) glp_ntt_pass_kernel(GlpNttPassArgs a) {
-    using ST = GlpSteps<LOG_R>;
+template <int LOG_R, int MODE, bool INV, int LOG_E = 4>
+__global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(GlpNttPassArgs a) {
+    using ST = GlpSteps<LOG_R, LOG_E>;
     constexpr u32 R = 1u << LOG_R;
+    constexpr u32 E = 1u << LOG_E;
     GLP_DYN_LDS(lds);
 
     const u32 log_c = a.log_c;
     const u32 C = 1u << log_c;
-    const u32 NT = (R << log_c) >> 4;        // == blockDim.x (checked on the host)
+    const u32 NT = (R << log_c) >> LOG_E;    // == blockDim.x (checked on the host)
     const u32 tid = threadIdx.x;
     const u32 ldA = C + 1;                   // layout A: [row][C+1]
     u64 tile = blockIdx.x;
@@ -167,14 +169,14 @@ __global__ void __launch_bounds__(1024) glp_ntt_pass_kernel(GlpNttPassArgs a) {
     }
     const u64 total_rows = (u64)a.batch << log_rows;
 
-    u64 x[16];
+    u64 x[E];
 
     glp_static_for<0, ST::S>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
         constexpr int q = ST::q(t);
         constexpr u32 r = 1u << q;
         constexpr int lsg = ST::log_sigma(t);
-        constexpr u32 G = 16u / r;           // units per thread in this step
+        constexpr u32 G = E / r;             // units per thread in this step
         constexpr bool first = (t == 0), last = (t == ST::S - 1);
 
         // ---- decode + load ---------------------------------------------------------
@@ -256,14 +258,14 @@ __global__ void __launch_bounds__(1024) glp_ntt_pass_kernel(GlpNttPassArgs a) {
                 });
             } else {
                 // inter-pass twiddle of a STRIP pass: X[k] *= w_N^{j' k}, j' = lo0 + col.  The 16
-                // outputs of this work-item are k = k0 + d*(R/16), so the factors form a geometric
+                // outputs of this work-item are k = k0 + d*(R/r), so the factors form a geometric
                 // progression: two table look-ups (base, ratio) and a running product instead
                 // of 16 pairs of gathered loads.
                 u64 tw = 1, ratio = 1;
                 if constexpr (MODE == GLP_STRIP) {
                     const u32 log_N = LOG_R + a.log_m;
                     const u64 jq = (u64)(lo0 + col);
-                    const u64 e0 = jq * glp_digit_reverse<LOG_R>(row0);      // < N <= 2^32
+                    const u64 e0 = jq * glp_digit_reverse<LOG_R, LOG_E>(row0);      // < N <= 2^32
                     const u64 e1 = jq << (LOG_R - q);                        // j' * R/r
                     if (log_N <= 12) {
                         tw = a.tw_lo[e0];
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(1024) glp_ntt_pass_kernel(GlpNttPassArgs a) {
                     constexpr int d = decltype(d_)::value;
                     u64 v = x[g * r + glp_bitrev_c(d, q)];
                     const u32 pos = row0 + (u32)d;                  // sigma == 1 in the last step
-                    const u32 k = glp_digit_reverse<LOG_R>(pos);    // natural output index in [0,R)
+                    const u32 k = glp_digit_reverse<LOG_R, LOG_E>(pos);    // natural output index in [0,R)
                     if constexpr (MODE == GLP_STRIP) {
                         v = gl_mul(v, tw);
                         if constexpr (d + 1 < (int)r) tw = gl_mul(tw, ratio);

@@ -20,6 +20,7 @@ struct GlpPass {
     int log_r;     // tile transform size
     int mode;      // GLP_STRIP / GLP_FINAL_T / GLP_FINAL_ROWS
     int log_c;     // columns per tile
+    int log_e;     // elements per work-item (4 or 5)
     int log_m;     // STRIP: axis stride (log2); FINAL: 0
     int in_buf;    // GLP_BUF_*
     int out_buf;
@@ -40,16 +41,24 @@ static inline int glp_default_log_c(int log_r) {
     return tile_log - log_r;
 }
 
-// Parse "r:c,r:c,..." (log2 radix : log2 columns per pass); returns number of passes or 0.
-static inline int glp_parse_plan(const char* s, int* lr, int* lc) {
+// radix-32 register steps exist (are instantiated) only for the tile sizes they shorten
+static inline int glp_has_e5(int log_r) { return log_r == 9 || log_r == 10; }
+static inline int glp_default_log_e(int log_r) { (void)log_r; return 4; }
+
+// Parse "r:c[:e],r:c[:e],..." (log2 radix : log2 columns [: log2 elements per work-item]);
+// returns number of passes or 0.
+static inline int glp_parse_plan(const char* s, int* lr, int* lc, int* le = nullptr) {
     int n = 0;
     while (s && *s && n < GLP_MAX_PASSES) {
-        int r = 0, c = -1, used = 0;
-        if (sscanf(s, "%d:%d%n", &r, &c, &used) < 2) {
-            if (sscanf(s, "%d%n", &r, &used) < 1) return 0;
-            c = -1;
+        int r = 0, c = -1, e = -1, used = 0;
+        if (sscanf(s, "%d:%d:%d%n", &r, &c, &e, &used) < 3) {
+            e = -1;
+            if (sscanf(s, "%d:%d%n", &r, &c, &used) < 2) {
+                if (sscanf(s, "%d%n", &r, &used) < 1) return 0;
+                c = -1;
+            }
         }
-        lr[n] = r; lc[n] = c; n++;
+        lr[n] = r; lc[n] = c; if (le) le[n] = e; n++;
         s += used;
         if (*s == ',') s++;
     }
@@ -63,9 +72,10 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
     pl->log_n = log_n;
     pl->rev = rev;
     if (log_n < GLP_MIN_LOG_R || log_n > 32) return -1;
-    int lr[GLP_MAX_PASSES], lc[GLP_MAX_PASSES], np = 0;
+    int lr[GLP_MAX_PASSES], lc[GLP_MAX_PASSES], le[GLP_MAX_PASSES], np = 0;
+    for (int i = 0; i < GLP_MAX_PASSES; i++) le[i] = -1;
     if (ovr && *ovr) {
-        np = glp_parse_plan(ovr, lr, lc);
+        np = glp_parse_plan(ovr, lr, lc, le);
         int sum = 0;
         for (int i = 0; i < np; i++) sum += lr[i];
         if (np == 0 || sum != log_n) np = 0;   // ignore an override that does not fit this size
@@ -78,7 +88,7 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
             int base = log_n / np, extra = log_n % np;
             for (int i = 0; i < np; i++) lr[i] = base + (i < extra ? 1 : 0);
         }
-        for (int i = 0; i < np; i++) lc[i] = -1;
+        for (int i = 0; i < np; i++) { lc[i] = -1; le[i] = -1; }
     }
     if (np > GLP_MAX_PASSES) return -1;
     pl->npass = np;
@@ -91,17 +101,21 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
         int last = (i == np - 1);
         ps->mode = last ? ((rev || np == 1) ? GLP_FINAL_ROWS : GLP_FINAL_T) : GLP_STRIP;
         ps->log_m = last ? 0 : rem;
+        int e = le[i] >= 4 ? le[i] : glp_default_log_e(lr[i]);
+        if (e != 4 && !(e == 5 && glp_has_e5(lr[i]))) return -1;
+        ps->log_e = e;
+        const int tmin = 6 + e, tmax = 10 + e;              // 64 .. 1024 threads
         int c = lc[i] >= 0 ? lc[i] : glp_default_log_c(lr[i]);
         if (lc[i] < 0) {
             // small batches: prefer more, narrower tiles until the launch fills the chip
             // (>= 2 workgroups per CU), but never narrower than 32-byte segments
-            while (c > 2 && c + lr[i] > 10 && ((batch << log_n) >> (lr[i] + c)) < 512) c--;
+            while (c > 2 && c + lr[i] > tmin && ((batch << log_n) >> (lr[i] + c)) < 512) c--;
         }
-        if (c + lr[i] < 10) c = 10 - lr[i];                 // at least one wavefront of threads
-        if (c + lr[i] > 14) c = 14 - lr[i];                 // at most 1024 threads
+        if (c + lr[i] < tmin) c = tmin - lr[i];             // at least one wavefront of threads
+        if (c + lr[i] > tmax) c = tmax - lr[i];             // at most 1024 threads
         if (!last && c > rem) c = rem;                      // strip no wider than the axis stride
         if (last && ps->mode == GLP_FINAL_T && c > log_n - lr[i]) c = log_n - lr[i];
-        if (c + lr[i] < 10 || c < 0) return -1;
+        if (c + lr[i] < tmin || c < 0) return -1;
         // LDS footprint must fit 160 KiB: max(R*(C+1), C*(R+1)) * 8
         while (c > 0) {
             unsigned long long R = 1ull << lr[i], C = 1ull << c;
@@ -109,7 +123,7 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
             if (el * 8 <= 160 * 1024) break;
             c--;
         }
-        if (c + lr[i] < 10) return -1;
+        if (c + lr[i] < tmin) return -1;
         ps->log_c = c;
     }
     // buffer routing.  STRIP passes may run in place; FINAL_T may not.
@@ -141,7 +155,7 @@ static inline size_t glp_pass_lds_bytes(const GlpPass* ps) {
     unsigned long long a = R * (C + 1), b = (ps->mode == GLP_FINAL_ROWS) ? C * (R + 1) : 0;
     return (size_t)((a > b ? a : b) * 8);
 }
-static inline unsigned glp_pass_threads(const GlpPass* ps) { return 1u << (ps->log_r + ps->log_c - 4); }
+static inline unsigned glp_pass_threads(const GlpPass* ps) { return 1u << (ps->log_r + ps->log_c - ps->log_e); }
 static inline unsigned long long glp_pass_grid(const GlpPass* ps, int log_n, unsigned long long batch) {
     if (ps->mode == GLP_STRIP) return batch << (log_n - ps->log_r - ps->log_c);
     unsigned long long rows = batch << (log_n - ps->log_r);

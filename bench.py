@@ -99,11 +99,10 @@ def cpu_baseline(log_n, seconds_target=15.0):
 
 
 SWEEP = {
-    (20, 128): ["10:4,10:4", "10:3,10:3", "10:2,10:2", "8:4,12:2", "12:2,8:4", "7:5,7:5,6:6", "11:3,9:3", "9:3,11:3",
-                "9:4,11:3", "11:3,9:4", "12:1,8:4", "8:4,12:1", "10:3,10:4", "10:4,10:3"],
-    (22, 32): ["11:3,11:3", "11:2,11:2", "8:4,7:5,7:5", "10:4,12:2", "12:2,10:4", "10:3,12:2", "12:2,10:3", "12:1,10:3", "8:4,8:4,6:6"],
-    (24, 8): ["12:2,12:2", "12:1,12:1", "8:4,8:4,8:4", "12:2,6:4,6:4", "10:4,7:5,7:5", "6:6,6:6,12:2", "8:4,8:4,8:5", "9:4,9:4,6:6",
-              "12:2,12:1", "12:1,12:2"],
+    (20, 128): ["10:3,10:3", "8:4,12:2", "12:2,8:4", "7:5,7:5,6:6", "10:3:5,10:3:5", "10:2:5,10:2:5", "10:4:5,10:4:5", "10:3:5,10:3",
+                "10:3,10:3:5", "10:4:5,10:3:5", "10:4:5,10:2:5", "9:3:5,11:3", "8:4,8:4,4:6"],
+    (22, 32): ["11:3,11:3", "8:4,7:5,7:5", "12:2,10:3", "12:2,10:3:5", "8:4,8:4,6:6", "10:4:5,6:4,6:4", "8:4,7:5,7:5"],
+    (24, 8): ["12:2,12:2", "8:4,8:4,8:4", "10:4:5,7:5,7:5", "8:4,8:4,8:5", "9:3:5,9:3:5,6:6", "10:4:5,10:3:5,4:6"],
     (20, 1): ["10:4,10:4", "10:3,10:3", "10:2,10:2", "8:4,12:2", "12:2,8:4", "7:5,7:5,6:6"],
     (24, 1): ["12:2,12:2", "12:1,12:1", "8:4,8:4,8:4", "10:4,7:5,7:5"],
 }

@@ -28,7 +28,11 @@ struct EmuBackend {
         auto go = [&](auto mode_, auto inv_) {
             constexpr int MODE = decltype(mode_)::value;
             constexpr bool INV = decltype(inv_)::value != 0;
-            glp_emu_launch(grid, block, lds, [&] { glp_ntt_pass_kernel<LR, MODE, INV>(a); });
+            if (ps.log_e == 5) {
+                if constexpr (LR == 9 || LR == 10) glp_emu_launch(grid, block, lds, [&] { glp_ntt_pass_kernel<LR, MODE, INV, 5>(a); });
+            } else {
+                glp_emu_launch(grid, block, lds, [&] { glp_ntt_pass_kernel<LR, MODE, INV, 4>(a); });
+            }
         };
         int key = ps.mode * 2 + (inv ? 1 : 0);
         switch (key) {
