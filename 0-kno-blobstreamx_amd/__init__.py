@@ -39,6 +39,17 @@ _ERR = {-1: "GLP_E_INVALID", -2: "GLP_E_NODEVICE", -3: "GLP_E_HIP", -4: "GLP_E_N
 _lib = None
 
 
+class FriConfig(ctypes.Structure):
+    _fields_ = [("log_n", ctypes.c_uint32), ("rate_bits", ctypes.c_uint32), ("cap_height", ctypes.c_uint32),
+                ("arity_bits", ctypes.c_uint32), ("final_poly_bits", ctypes.c_uint32), ("num_queries", ctypes.c_uint32),
+                ("pow_bits", ctypes.c_uint32), ("shift", ctypes.c_uint64)]
+
+
+class FriBatch(ctypes.Structure):
+    _fields_ = [("d_coeffs", ctypes.c_void_p), ("d_lde", ctypes.c_void_p), ("d_digests", ctypes.c_void_p),
+                ("h_cap", ctypes.c_void_p), ("n_polys", ctypes.c_uint32)]
+
+
 def load_library():
     """dlopen libglprover.so; raises GlpError (never falls back) when it is missing."""
     global _lib
@@ -87,6 +98,15 @@ def load_library():
         "glp_fri_fold2": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint64, _vp]),
         "glp_sha256_trace": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp]),
         "glp_sha512_trace": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp]),
+        "glp_challenger_new": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+        "glp_challenger_free": (None, [_vp]),
+        "glp_challenger_observe": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+        "glp_challenger_challenges": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+        "glp_eval_at_ext": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp]),
+        "glp_pow_grind": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp]),
+        "glp_fri_prove": (ctypes.c_int, [_vp, ctypes.POINTER(FriConfig), ctypes.POINTER(FriBatch), ctypes.c_uint32,
+                                         ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_size_t)]),
+        "glp_free_host": (None, [_vp]),
     }
     for name, (res, args) in opt.items():
         if hasattr(lib, name):
@@ -373,6 +393,44 @@ class Prover:
                 b.free()
         return dig, tr
 
+    # ---- transcript + FRI opening proof (rows a5, a8, a12; build-defined protocol) ---------
+    def challenger(self):
+        return Challenger(self)
+
+    def eval_at_ext(self, d_coeffs, log_n, n_polys, z, stride=None):
+        zz = np.ascontiguousarray(z, dtype=np.uint64)
+        out = np.zeros((n_polys, 2), dtype=np.uint64)
+        self._chk(self.lib.glp_eval_at_ext(self.ctx, _ptr(d_coeffs), stride or (1 << log_n), log_n, n_polys, zz.ctypes.data,
+                                           out.ctypes.data), "glp_eval_at_ext")
+        return out
+
+    def pow_grind(self, seed4, pow_bits):
+        sd = np.ascontiguousarray(seed4, dtype=np.uint64)
+        nonce = ctypes.c_uint64()
+        self._chk(self.lib.glp_pow_grind(self.ctx, sd.ctypes.data, pow_bits, ctypes.byref(nonce)), "glp_pow_grind")
+        return nonce.value
+
+    def fri_prove(self, batches, rate_bits, cap_height, arity_bits=4, final_poly_bits=5, num_queries=28, pow_bits=16,
+                  shift=COSET_SHIFT):
+        """batches: PolynomialBatch objects of equal log_n committed with (rate_bits, cap_height).
+        Returns the proof bytes (little-endian u64 words)."""
+        log_n = batches[0].log_n
+        cfg = FriConfig(log_n, rate_bits, cap_height, arity_bits, final_poly_bits, num_queries, pow_bits, shift)
+        arr = (FriBatch * len(batches))()
+        keep = []
+        for i, b in enumerate(batches):
+            assert b.log_n == log_n and b.rate_bits == rate_bits
+            cap = np.ascontiguousarray(b.cap, dtype=np.uint64)
+            keep.append(cap)
+            arr[i] = FriBatch(_ptr(b.coeffs), _ptr(b.lde), _ptr(b.digests), cap.ctypes.data, b.n_polys)
+        proof = _vp()
+        ln = ctypes.c_size_t()
+        self._chk(self.lib.glp_fri_prove(self.ctx, ctypes.byref(cfg), arr, len(batches), ctypes.byref(proof), ctypes.byref(ln)),
+                  "glp_fri_prove")
+        data = ctypes.string_at(proof.value, ln.value)
+        self.lib.glp_free_host(proof)
+        return data
+
     def transpose(self, mat):
         m = np.ascontiguousarray(mat, dtype=np.uint64)
         rows, cols = m.shape
@@ -394,6 +452,31 @@ def sha_pad(msg: bytes, block: int, blocks: int = None) -> bytes:
         assert need == blocks, "message does not pad to the requested number of blocks"
     pad = need * block - len(msg) - 1 - lenbytes
     return msg + b"\x80" + b"\x00" * pad + (8 * len(msg)).to_bytes(lenbytes, "big")
+
+
+class Challenger:
+    """Host-side Fiat-Shamir transcript of the library (glp_challenger_*)"""
+
+    def __init__(self, prover):
+        self.lib = prover.lib
+        h = _vp()
+        prover._chk(self.lib.glp_challenger_new(prover.ctx, ctypes.byref(h)), "glp_challenger_new")
+        self.h = h
+
+    def observe(self, elems):
+        a = np.ascontiguousarray(elems, dtype=np.uint64).reshape(-1)
+        if self.lib.glp_challenger_observe(self.h, a.ctypes.data, a.size) != 0:
+            raise GlpError("glp_challenger_observe: non-canonical element")
+
+    def challenges(self, n):
+        out = np.zeros(n, dtype=np.uint64)
+        self.lib.glp_challenger_challenges(self.h, out.ctypes.data, n)
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.glp_challenger_free(self.h)
+            self.h = None
 
 
 class PolynomialBatch:

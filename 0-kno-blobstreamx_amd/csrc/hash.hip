@@ -5,13 +5,7 @@
 #include "glp_ctx.h"
 #include "hash_kernels.cuh"
 
-struct glp_hash_state {
-    u64* d_consts = nullptr;   // rc[360] | circ[12] | diag[12]
-    bool have_consts = false;
-    bool small_mds = false;
-    u32* d_k256 = nullptr;
-    u64* d_k512 = nullptr;
-};
+#include "hash_state.h"
 
 int glp_ntt_table(glp_ctx* c, int log_N, int inv, const u64** lo, const u64** hi);   // glprover.hip
 
@@ -41,10 +35,11 @@ static const u64 K512[80] = {
     0x113f9804bef90daeull, 0x1b710b35131c471bull, 0x28db77f523047d84ull, 0x32caab7b40c72493ull, 0x3c9ebe0a15c9bebcull,
     0x431d67c49c100d4cull, 0x4cc5d4becb3e42b6ull, 0x597f299cfc657e2aull, 0x5fcb6fab3ad6faecull, 0x6c44198c4a475817ull};
 
-static glp_hash_state* hs(glp_ctx* c) {
+glp_hash_state* glp_hash_get(glp_ctx* c) {
     if (!c->hash) c->hash = new glp_hash_state();
     return c->hash;
 }
+static glp_hash_state* hs(glp_ctx* c) { return glp_hash_get(c); }
 
 void glp_hash_destroy(glp_ctx* c) {
     if (!c || !c->hash) return;
@@ -77,6 +72,7 @@ extern "C" int glp_set_poseidon_constants(glp_ctx* c, const uint64_t* rc, size_t
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!h->d_consts) GLP_HIPCHK(c, hipMalloc((void**)&h->d_consts, 384 * 8));
     GLP_HIPCHK(c, hipMemcpy(h->d_consts, all.data(), 384 * 8, hipMemcpyHostToDevice));
+    h->h_consts = all;
     h->have_consts = true;
     h->small_mds = small;
     return GLP_OK;

@@ -110,6 +110,48 @@ int glp_merkle_from_polys(glp_ctx* ctx, const uint64_t* d_polys, uint64_t poly_s
 int glp_fri_fold2(glp_ctx* ctx, const uint64_t* d_evals, uint64_t* d_out, uint32_t log_n, uint64_t shift,
                   const uint64_t* h_beta);
 
+/* ---- Fiat-Shamir challenger (row a5; upstream name recalled: plonky2::iop::challenger) ----
+ * Poseidon duplex sponge (width 12, rate 8, overwrite mode) run on the HOST with the injected
+ * constants: observing invalidates pending outputs; a challenge absorbs whatever is buffered
+ * and pops outputs from the end of state[0..8).  Build-defined (transcript order unpinned). */
+typedef struct glp_challenger glp_challenger;
+int glp_challenger_new(glp_ctx* ctx, glp_challenger** out);
+void glp_challenger_free(glp_challenger* ch);
+int glp_challenger_observe(glp_challenger* ch, const uint64_t* h_elems, size_t n);
+int glp_challenger_challenges(glp_challenger* ch, uint64_t* h_out, size_t n);
+
+/* ---- FRI opening proof (rows a8, a12; upstream names recalled: fri::prover::fri_proof,
+ *      PolynomialBatch::prove_openings).  Protocol + byte layout are build-defined: DESIGN.md §3.5 */
+/* f_p(z) for n_polys coefficient-form polynomials (z in the quadratic extension, h_z = 2 u64):
+ * h_out receives n_polys pairs */
+int glp_eval_at_ext(glp_ctx* ctx, const uint64_t* d_coeffs, uint64_t poly_stride, uint32_t log_n, uint32_t n_polys,
+                    const uint64_t* h_z, uint64_t* h_out);
+/* smallest nonce with the top pow_bits bits of Poseidon(seed[0..4], nonce, 0...)[0] clear */
+int glp_pow_grind(glp_ctx* ctx, const uint64_t* h_seed4, uint32_t pow_bits, uint64_t* h_nonce);
+
+typedef struct {
+    uint32_t log_n;            /* every committed polynomial has 2^log_n coefficients */
+    uint32_t rate_bits;        /* LDE blow-up used when the batches were committed */
+    uint32_t cap_height;       /* Merkle cap height of the batches and (clamped) of the fold layers */
+    uint32_t arity_bits;       /* fold arity 2^arity_bits per committed layer */
+    uint32_t final_poly_bits;  /* stop folding when the degree bound is <= 2^final_poly_bits (+ remainder) */
+    uint32_t num_queries;
+    uint32_t pow_bits;
+    uint64_t shift;            /* coset shift of the LDE domain (7) */
+} glp_fri_config;
+typedef struct {               /* one committed batch, as produced by ifft -> glp_lde_coset(BITREV) -> glp_merkle_from_polys */
+    const uint64_t* d_coeffs;  /* [n_polys][2^log_n], dense */
+    const uint64_t* d_lde;     /* [n_polys][2^(log_n+rate_bits)], bit-reversed evaluation order */
+    const uint64_t* d_digests; /* Merkle digests of that LDE (layout of glp_merkle) */
+    const uint64_t* h_cap;     /* its cap: 4 << min(cap_height, log_n+rate_bits) words (host) */
+    uint32_t n_polys;
+} glp_fri_batch;
+/* proves the openings of every polynomial of every batch at one transcript-derived point.
+ * *proof is malloc'd by the library (little-endian u64 words), free with glp_free_host. */
+int glp_fri_prove(glp_ctx* ctx, const glp_fri_config* cfg, const glp_fri_batch* batches, uint32_t n_batches,
+                  uint8_t** proof, size_t* proof_len);
+void glp_free_host(void* p);
+
 /* ---- witness generation (rows a9; upstream names recalled: curta SHA-256/SHA-512 chips) */
 /* n_msgs messages, each already padded to blocks_per_msg 64-byte blocks, [n_msgs][blocks*64].
  * d_digests: [n_msgs][8] u32 (big-endian words as u32).  d_trace (may be NULL):

@@ -53,6 +53,7 @@ def oracle():
     lib.orc_fri_fold2.argtypes = [u64p, u64p, ctypes.c_uint, ctypes.c_uint64, u64p]
     lib.orc_sha256.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_void_p]
     lib.orc_sha512.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_void_p]
+    lib.orc_hash_or_noop.argtypes = [u64p, ctypes.c_uint64, u64p]
     return lib
 
 
@@ -106,6 +107,12 @@ def emu():
                                      ctypes.c_void_p]
     lib.emu_sha512_trace.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]
+    lib.emu_challenger.argtypes = [u64p, ctypes.c_int, u64p, ctypes.c_uint64, u64p]
+    lib.emu_eval_at_ext.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, u64p, u64p]
+    lib.emu_fri_combine.argtypes = [u64p, ctypes.c_uint32, ctypes.c_uint32, u64p, u64p, u64p, ctypes.c_uint64, u64p, ctypes.c_int,
+                                    ctypes.c_int]
+    lib.emu_pow.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, u64p, ctypes.c_int,
+                            ctypes.POINTER(ctypes.c_ulonglong)]
     return lib
 
 

@@ -151,3 +151,62 @@ extern "C" int emu_sha512_trace(const uint8_t* blocks, u64 n_msgs, u32 bpm, u64*
     glp_emu_launch(grid, block, 0, [&] { glp_sha512_trace_kernel<0>(blocks, n_msgs, bpm, digests, trace, k512); });
     return 0;
 }
+
+// ---- FRI kernels + challenger under emulation ---------------------------------------------
+#include "../../0-kno-blobstreamx_amd/csrc/fri_kernels.cuh"
+#include "../../0-kno-blobstreamx_amd/csrc/challenger.h"
+
+extern "C" int emu_challenger(const u64* consts384, int small, const u64* script, u64 n_script, u64* out) {
+    // script: sequence of ops: (0, value) = observe value ; (1, _) = emit one challenge
+    glp_challenger ch;
+    memset(ch.state, 0, sizeof(ch.state));
+    ch.n_in = ch.n_out = 0;
+    ch.consts.assign(consts384, consts384 + 384);
+    ch.small_mds = small != 0;
+    u64 k = 0;
+    for (u64 i = 0; i < n_script; i++) {
+        if (script[2 * i] == 0) ch.observe(script[2 * i + 1]);
+        else out[k++] = ch.challenge();
+    }
+    return (int)k;
+}
+
+extern "C" int emu_eval_at_ext(const u64* coeffs, u64 stride, u32 log_n, u32 n_polys, const u64* z, u64* out) {
+    const u64 n = 1ull << log_n, nhi = (n + 255) / 256;
+    std::vector<u64> lo(512), hi(2 * nhi), zp(2 * n);
+    gl_ext2 zz{z[0], z[1]}, t{1, 0};
+    for (int j = 0; j < 256; j++) { lo[2 * j] = t.a; lo[2 * j + 1] = t.b; t = gl_ext_mul(t, zz); }
+    gl_ext2 z256 = t; t = gl_ext2{1, 0};
+    for (u64 j = 0; j < nhi; j++) { hi[2 * j] = t.a; hi[2 * j + 1] = t.b; t = gl_ext_mul(t, z256); }
+    glp_emu_launch((unsigned)((n + 255) / 256), 256, 0, [&] { glp_ext_powers_kernel<0>(zp.data(), n, lo.data(), hi.data()); });
+    const u32 n_chunks = (u32)((n + GLP_EVAL_CHUNK - 1) / GLP_EVAL_CHUNK);
+    std::vector<u64> part((size_t)n_polys * n_chunks * 2);
+    glp_emu_launch(n_polys * n_chunks, 256, 0, [&] { glp_eval_ext_kernel<0>(coeffs, stride, n, n_chunks, zp.data(), part.data()); });
+    for (u32 p = 0; p < n_polys; p++) {
+        u64 a = 0, b = 0;
+        for (u32 k = 0; k < n_chunks; k++) { a = gl_add(a, part[2 * ((size_t)p * n_chunks + k)]); b = gl_add(b, part[2 * ((size_t)p * n_chunks + k) + 1]); }
+        out[2 * p] = a; out[2 * p + 1] = b;
+    }
+    return 0;
+}
+
+extern "C" int emu_fri_combine(const u64* lde, u32 n_polys, u32 log_N, const u64* alpha_pow, const u64* Y, const u64* z, u64 shift,
+                               u64* acc, int first, int finish) {
+    std::vector<u64> lo(glp_table_lo_len(log_N)), hi(glp_table_hi_len(log_N) ? glp_table_hi_len(log_N) : 1);
+    glp_fill_table(log_N, 0, lo.data(), hi.data());
+    GlpCombineArgs a;
+    a.lde = lde; a.poly_stride = 1ull << log_N; a.n_polys = n_polys; a.alpha_pow = alpha_pow; a.acc = acc; a.log_N = log_N;
+    a.first = first; a.finish = finish; a.Y = gl_ext2{Y[0], Y[1]}; a.z = gl_ext2{z[0], z[1]}; a.shift = shift;
+    a.w_lo = lo.data(); a.w_hi = glp_table_hi_len(log_N) ? hi.data() : nullptr;
+    const u64 threads = (1ull << log_N) / 4;
+    glp_emu_launch((unsigned)((threads + 63) / 64), 64, 0, [&] { glp_fri_combine_kernel<0>(a); });
+    return 0;
+}
+
+extern "C" int emu_pow(const u64* seed, u64 base, u64 count, u32 pow_bits, const u64* consts384, int small, unsigned long long* found) {
+    GlpPoseidonConsts k{consts384, consts384 + 360, consts384 + 372};
+    *found = ~0ull;
+    if (small) glp_emu_launch((unsigned)((count + 63) / 64), 64, 0, [&] { glp_pow_kernel<true>(seed, base, count, pow_bits, found, k); });
+    else glp_emu_launch((unsigned)((count + 63) / 64), 64, 0, [&] { glp_pow_kernel<false>(seed, base, count, pow_bits, found, k); });
+    return 0;
+}

@@ -26,6 +26,7 @@ inline glp_emu_dim3 blockDim, gridDim;
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__
+#define __shared__ static   // one workgroup at a time: a function-local static is shared by its threads
 
 namespace glp_emu {
 inline std::barrier<>* block_barrier = nullptr;
@@ -43,6 +44,12 @@ inline unsigned __brev(unsigned v) {
     unsigned r = 0;
     for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
     return r;
+}
+#include <mutex>
+inline void glp_emu_atomic_min(unsigned long long* p, unsigned long long v) {
+    static std::mutex m;
+    std::lock_guard<std::mutex> g(m);
+    if (v < *p) *p = v;
 }
 // 64-wide wavefront shuffles (all lanes of the wave must call)
 inline unsigned long long glp_emu_shfl(unsigned long long v, unsigned src_lane) {
