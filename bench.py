@@ -177,6 +177,25 @@ def hash_bench():
         print(json.dumps(res), flush=True)
         for b in (co, lde, dig):
             b.free()
+    # the whole opening proof at configs[1] scale: wires 135 + Z/partial products 20 + quotient 16 polynomials of 2^20
+    for log_n, polys in ((16, [135, 20, 16]), (20, [135, 20, 16])):
+        t0 = time.perf_counter()
+        batches = []
+        for k, npol in enumerate(polys):
+            d = pr.to_device(splitmix_fill(npol << log_n, 10 + k).reshape(npol, 1 << log_n))
+            pr.ntt_(d, log_n, npol, inverse=True)
+            batches.append(pkg.PolynomialBatch.from_coeffs(pr, d, npol, log_n, 3, 4))
+        pr.sync()
+        t1 = time.perf_counter()
+        proof = pr.fri_prove(batches, 3, 4, arity_bits=4, final_poly_bits=5, num_queries=28, pow_bits=16)
+        t2 = time.perf_counter()
+        proof2 = pr.fri_prove(batches, 3, 4, arity_bits=4, final_poly_bits=5, num_queries=28, pow_bits=16)
+        t3 = time.perf_counter()
+        print(json.dumps({"stage": "commit+fri_prove", "log_n": log_n, "polys": polys, "commit_s_incl_h2d": round(t1 - t0, 4),
+                          "fri_prove_s_first": round(t2 - t1, 4), "fri_prove_s": round(t3 - t2, 4), "proof_bytes": len(proof),
+                          "deterministic": proof == proof2}), flush=True)
+        for b in batches:
+            b.free()
     pr.close()
 
 
