@@ -42,12 +42,13 @@ _lib = None
 class FriConfig(ctypes.Structure):
     _fields_ = [("log_n", ctypes.c_uint32), ("rate_bits", ctypes.c_uint32), ("cap_height", ctypes.c_uint32),
                 ("arity_bits", ctypes.c_uint32), ("final_poly_bits", ctypes.c_uint32), ("num_queries", ctypes.c_uint32),
-                ("pow_bits", ctypes.c_uint32), ("shift", ctypes.c_uint64)]
+                ("pow_bits", ctypes.c_uint32), ("shift", ctypes.c_uint64), ("n_points", ctypes.c_uint32),
+                ("point_mult", ctypes.c_uint64 * 4)]
 
 
 class FriBatch(ctypes.Structure):
     _fields_ = [("d_coeffs", ctypes.c_void_p), ("d_lde", ctypes.c_void_p), ("d_digests", ctypes.c_void_p),
-                ("h_cap", ctypes.c_void_p), ("n_polys", ctypes.c_uint32)]
+                ("h_cap", ctypes.c_void_p), ("n_polys", ctypes.c_uint32), ("open_mask", ctypes.c_uint32)]
 
 
 def load_library():
@@ -107,6 +108,11 @@ def load_library():
         "glp_fri_prove": (ctypes.c_int, [_vp, ctypes.POINTER(FriConfig), ctypes.POINTER(FriBatch), ctypes.c_uint32,
                                          ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_size_t)]),
         "glp_free_host": (None, [_vp]),
+        "glp_plonk_setup": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32,
+                                           ctypes.POINTER(_vp)]),
+        "glp_plonk_free": (None, [_vp]),
+        "glp_plonk_prove": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp),
+                                           ctypes.POINTER(ctypes.c_size_t)]),
     }
     for name, (res, args) in opt.items():
         if hasattr(lib, name):
@@ -411,18 +417,22 @@ class Prover:
         return nonce.value
 
     def fri_prove(self, batches, rate_bits, cap_height, arity_bits=4, final_poly_bits=5, num_queries=28, pow_bits=16,
-                  shift=COSET_SHIFT):
+                  shift=COSET_SHIFT, point_mults=(1,), open_masks=None):
         """batches: PolynomialBatch objects of equal log_n committed with (rate_bits, cap_height).
-        Returns the proof bytes (little-endian u64 words)."""
+        point_mults: opening points zeta*m; open_masks[i]: bitmask of points batch i is opened at
+        (default: every batch at every point).  Returns the proof bytes (little-endian u64 words)."""
         log_n = batches[0].log_n
-        cfg = FriConfig(log_n, rate_bits, cap_height, arity_bits, final_poly_bits, num_queries, pow_bits, shift)
+        pm = (ctypes.c_uint64 * 4)(*(list(point_mults) + [0] * (4 - len(point_mults))))
+        cfg = FriConfig(log_n, rate_bits, cap_height, arity_bits, final_poly_bits, num_queries, pow_bits, shift, len(point_mults), pm)
+        if open_masks is None:
+            open_masks = [(1 << len(point_mults)) - 1] * len(batches)
         arr = (FriBatch * len(batches))()
         keep = []
         for i, b in enumerate(batches):
             assert b.log_n == log_n and b.rate_bits == rate_bits
             cap = np.ascontiguousarray(b.cap, dtype=np.uint64)
             keep.append(cap)
-            arr[i] = FriBatch(_ptr(b.coeffs), _ptr(b.lde), _ptr(b.digests), cap.ctypes.data, b.n_polys)
+            arr[i] = FriBatch(_ptr(b.coeffs), _ptr(b.lde), _ptr(b.digests), cap.ctypes.data, b.n_polys, open_masks[i])
         proof = _vp()
         ln = ctypes.c_size_t()
         self._chk(self.lib.glp_fri_prove(self.ctx, ctypes.byref(cfg), arr, len(batches), ctypes.byref(proof), ctypes.byref(ln)),
@@ -452,6 +462,55 @@ def sha_pad(msg: bytes, block: int, blocks: int = None) -> bytes:
         assert need == blocks, "message does not pad to the requested number of blocks"
     pad = need * block - len(msg) - 1 - lenbytes
     return msg + b"\x80" + b"\x00" * pad + (8 * len(msg)).to_bytes(lenbytes, "big")
+
+
+class PlonkCircuit:
+    """Preprocessed build-defined circuit (glp_plonk_setup): constants (q, c0, c1) and sigma
+    columns committed once; prove(wires) returns the proof bytes.  DESIGN.md §3.6."""
+
+    def __init__(self, prover, consts, sigmas, rate_bits=3, cap_height=4):
+        self.prover = prover
+        c = np.ascontiguousarray(consts, dtype=np.uint64)
+        s = np.ascontiguousarray(sigmas, dtype=np.uint64)
+        self.n_wires, n = s.shape
+        self.log_n = n.bit_length() - 1
+        assert c.shape == (3, n) and 1 << self.log_n == n
+        dc, ds = prover.to_device(c), prover.to_device(s)
+        h = _vp()
+        prover._chk(prover.lib.glp_plonk_setup(prover.ctx, self.log_n, self.n_wires, dc.ptr, ds.ptr, rate_bits, cap_height,
+                                               ctypes.byref(h)), "glp_plonk_setup")
+        self.h = h
+        dc.free()
+        ds.free()
+
+    def prove(self, wires, num_queries=28, pow_bits=16):
+        w = np.ascontiguousarray(wires, dtype=np.uint64)
+        assert w.shape == (self.n_wires, 1 << self.log_n)
+        dw = self.prover.to_device(w)
+        try:
+            return self.prove_(dw, num_queries, pow_bits)
+        finally:
+            dw.free()
+
+    def prove_(self, d_wires, num_queries=28, pow_bits=16):
+        proof = _vp()
+        ln = ctypes.c_size_t()
+        self.prover._chk(self.prover.lib.glp_plonk_prove(self.prover.ctx, self.h, _ptr(d_wires), num_queries, pow_bits,
+                                                         ctypes.byref(proof), ctypes.byref(ln)), "glp_plonk_prove")
+        data = ctypes.string_at(proof.value, ln.value)
+        self.prover.lib.glp_free_host(proof)
+        return data
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.prover.lib.glp_plonk_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Challenger:

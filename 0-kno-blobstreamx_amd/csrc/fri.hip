@@ -167,95 +167,122 @@ extern "C" int glp_pow_grind(glp_ctx* c, const uint64_t* h_seed4, uint32_t pow_b
 extern "C" int glp_merkle(glp_ctx* c, const uint64_t* d_leaves, uint32_t leaf_len, uint32_t log_leaves, uint32_t cap_h,
                           uint64_t* d_digests, uint64_t* h_cap);
 extern "C" int glp_fri_fold2(glp_ctx* c, const uint64_t* d_evals, uint64_t* d_out, uint32_t log_n, uint64_t shift, const uint64_t* h_beta);
+extern "C" int glp_field_op(glp_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n);
 
-extern "C" int glp_fri_prove(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batch* batches, uint32_t n_batches,
-                             uint8_t** proof_out, size_t* proof_len) {
-    if (!c) return GLP_E_INVALID;
-    if (!cfg || !batches || n_batches == 0 || !proof_out || !proof_len) { glp_set_err(c, "glp_fri_prove: null argument"); return GLP_E_INVALID; }
-    *proof_out = nullptr; *proof_len = 0;
+int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batch* batches, uint32_t n_batches,
+                       glp_challenger& ch, std::vector<u64>& P) {
     const u32 log_n = cfg->log_n, rb = cfg->rate_bits, a = cfg->arity_bits, fb = cfg->final_poly_bits;
     const u32 log_N = log_n + rb;
     if (log_n < 2 || log_n > 26 || rb < 1 || rb > 6 || a < 1 || a > 5 || fb > log_n || cfg->num_queries == 0 || cfg->num_queries > 256 ||
-        cfg->pow_bits > 32 || cfg->cap_height > 12 || cfg->shift == 0 || cfg->shift >= GL_P) {
+        cfg->pow_bits > 32 || cfg->cap_height > 12 || cfg->shift == 0 || cfg->shift >= GL_P || cfg->n_points == 0 || cfg->n_points > 4) {
         glp_set_err(c, "glp_fri_prove: unsupported configuration");
         return GLP_E_INVALID;
     }
+    const u32 NP = cfg->n_points;
+    for (u32 p = 0; p < NP; p++) if (cfg->point_mult[p] == 0 || cfg->point_mult[p] >= GL_P) { glp_set_err(c, "glp_fri_prove: bad point multiplier"); return GLP_E_INVALID; }
     if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set (glp_set_poseidon_constants)"); return GLP_E_STATE; }
+    if (!cfg || !batches || n_batches == 0) { glp_set_err(c, "glp_fri_prove: null argument"); return GLP_E_INVALID; }
     const u64 n = 1ull << log_n, N = 1ull << log_N;
     const u32 cap0 = cfg->cap_height < log_N ? cfg->cap_height : log_N;
     u32 total_polys = 0;
     for (u32 b = 0; b < n_batches; b++) {
-        if (!batches[b].d_coeffs || !batches[b].d_lde || !batches[b].d_digests || !batches[b].h_cap || batches[b].n_polys == 0) {
+        if (!batches[b].d_coeffs || !batches[b].d_lde || !batches[b].d_digests || !batches[b].h_cap || batches[b].n_polys == 0 ||
+            batches[b].open_mask == 0 || (batches[b].open_mask >> NP)) {
             glp_set_err(c, "glp_fri_prove: batch %u incomplete", b);
             return GLP_E_INVALID;
         }
-        total_polys += batches[b].n_polys;
+        for (u32 p = 0; p < NP; p++) if ((batches[b].open_mask >> p) & 1u) total_polys += batches[b].n_polys;   // one opening per (point, poly)
+    }
+    {
+        bool p0 = false;
+        for (u32 b = 0; b < n_batches; b++) p0 = p0 || (batches[b].open_mask & 1u);
+        if (!p0) { glp_set_err(c, "glp_fri_prove: no batch is opened at point 0"); return GLP_E_INVALID; }
     }
     const u32 L = (log_n > fb) ? (log_n - fb) / a : 0;      // committed fold layers
     const u32 final_bits = log_n - a * L;                   // degree bound of the final polynomial
     if (final_bits + rb > 12) { glp_set_err(c, "glp_fri_prove: final polynomial too large (2^%u points) for host interpolation", final_bits + rb); return GLP_E_UNSUPPORTED; }
 
-    glp_challenger* chp = challenger_new(c);
-    if (!chp) return GLP_E_STATE;
-    std::unique_ptr<glp_challenger> ch_guard(chp);
-    glp_challenger& ch = *chp;
-    std::vector<u64> P;                                     // the proof, as u64 words
     auto put = [&](u64 v) { P.push_back(v); };
+    const size_t hdr0 = P.size();
 
     // header + caps
-    put(0x31304952464C4747ull /* "GGLFRI01" little-endian tag */);
+    put(0x32304952464C4747ull /* "GGLFRI02" little-endian tag */);
     put(log_n); put(rb); put(cap0); put(a); put(fb); put(cfg->num_queries); put(cfg->pow_bits); put(cfg->shift); put(n_batches);
-    for (u32 b = 0; b < n_batches; b++) put(batches[b].n_polys);
-    for (u64 w : P) ch.observe(w % GL_P);                   // bind the statement parameters
+    put(NP);
+    for (u32 p = 0; p < NP; p++) put(cfg->point_mult[p]);
+    for (u32 b = 0; b < n_batches; b++) { put(batches[b].n_polys); put(batches[b].open_mask); }
+    for (size_t k = hdr0; k < P.size(); k++) ch.observe(P[k] % GL_P);   // bind the statement parameters
     for (u32 b = 0; b < n_batches; b++)
         for (u32 i = 0; i < (4u << cap0); i++) { const u64 v = batches[b].h_cap[i]; if (v >= GL_P) { glp_set_err(c, "cap not canonical"); return GLP_E_INVALID; } put(v); ch.observe(v); }
 
-    // opening point and openings
+    // opening points z_p = zeta * mult_p and the openings, in (point, batch, polynomial) order
     const gl_ext2 zeta = ch.ext_challenge();
-    DevBuf zp;
-    int rc = build_zpowers(c, zeta, log_n, zp);
-    if (rc) return rc;
     std::vector<u64> openings(2 * (size_t)total_polys);
+    int rc;
     {
         size_t off = 0;
-        for (u32 b = 0; b < n_batches; b++) {
-            rc = eval_batch_at(c, batches[b].d_coeffs, n, log_n, batches[b].n_polys, zp.u(), openings.data() + off);
+        for (u32 p = 0; p < NP; p++) {
+            DevBuf zp;
+            rc = build_zpowers(c, gl_ext_scale(zeta, cfg->point_mult[p]), log_n, zp);
             if (rc) return rc;
-            off += 2 * (size_t)batches[b].n_polys;
+            for (u32 b = 0; b < n_batches; b++) {
+                if (!((batches[b].open_mask >> p) & 1u)) continue;
+                rc = eval_batch_at(c, batches[b].d_coeffs, n, log_n, batches[b].n_polys, zp.u(), openings.data() + off);
+                if (rc) return rc;
+                off += 2 * (size_t)batches[b].n_polys;
+            }
         }
     }
     for (u64 v : openings) { put(v); ch.observe(v); }
     const gl_ext2 alpha = ch.ext_challenge();
 
-    // alpha powers and Y = sum alpha^k y_k
+    // alpha powers (one per opening) ; per point Y_p = sum alpha^k y_k over that point's openings
     std::vector<u64> apow(2 * (size_t)total_polys);
-    gl_ext2 Y{0, 0};
     {
         gl_ext2 t{1, 0};
-        for (u32 k = 0; k < total_polys; k++) {
-            apow[2 * k] = t.a; apow[2 * k + 1] = t.b;
-            Y = gl_ext_add(Y, gl_ext_mul(t, gl_ext2{openings[2 * k], openings[2 * k + 1]}));
-            t = gl_ext_mul(t, alpha);
-        }
+        for (u32 k = 0; k < total_polys; k++) { apow[2 * k] = t.a; apow[2 * k + 1] = t.b; t = gl_ext_mul(t, alpha); }
     }
-    DevBuf d_apow, d_code;
+    DevBuf d_apow, d_code, d_tmp;
     GLP_HIPCHK(c, d_apow.alloc(apow.size() * 8));
     GLP_HIPCHK(c, hipMemcpyAsync(d_apow.p, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, c->stream));
     GLP_HIPCHK(c, d_code.alloc(N * 16));
+    if (NP > 1) GLP_HIPCHK(c, d_tmp.alloc(N * 16));
     const u64* w_lo = nullptr; const u64* w_hi = nullptr;
     rc = glp_ntt_table(c, (int)log_N, 0, &w_lo, &w_hi);
     if (rc) return rc;
     {
         u32 koff = 0;
-        for (u32 b = 0; b < n_batches; b++) {
-            GlpCombineArgs ca;
-            ca.lde = batches[b].d_lde; ca.poly_stride = N; ca.n_polys = batches[b].n_polys;
-            ca.alpha_pow = d_apow.u() + 2 * (size_t)koff;
-            ca.acc = d_code.u(); ca.log_N = log_N; ca.first = (b == 0); ca.finish = (b == n_batches - 1);
-            ca.Y = Y; ca.z = zeta; ca.shift = cfg->shift; ca.w_lo = w_lo; ca.w_hi = w_hi;
-            hipLaunchKernelGGL(glp_fri_combine_kernel<0>, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, c->stream, ca);
-            GLP_HIPCHK(c, hipGetLastError());
-            koff += batches[b].n_polys;
+        for (u32 p = 0; p < NP; p++) {
+            u32 nb_here = 0, last_b = 0;
+            for (u32 b = 0; b < n_batches; b++) if ((batches[b].open_mask >> p) & 1u) { nb_here++; last_b = b; }
+            if (nb_here == 0) continue;
+            gl_ext2 Y{0, 0};
+            {
+                u32 k = koff;
+                for (u32 b = 0; b < n_batches; b++) {
+                    if (!((batches[b].open_mask >> p) & 1u)) continue;
+                    for (u32 q = 0; q < batches[b].n_polys; q++, k++)
+                        Y = gl_ext_add(Y, gl_ext_mul(gl_ext2{apow[2 * k], apow[2 * k + 1]}, gl_ext2{openings[2 * k], openings[2 * k + 1]}));
+                }
+            }
+            u64* target = (p == 0) ? d_code.u() : d_tmp.u();
+            bool first = true;
+            for (u32 b = 0; b < n_batches; b++) {
+                if (!((batches[b].open_mask >> p) & 1u)) continue;
+                GlpCombineArgs ca;
+                ca.lde = batches[b].d_lde; ca.poly_stride = N; ca.n_polys = batches[b].n_polys;
+                ca.alpha_pow = d_apow.u() + 2 * (size_t)koff;
+                ca.acc = target; ca.log_N = log_N; ca.first = first; ca.finish = (b == last_b);
+                ca.Y = Y; ca.z = gl_ext_scale(zeta, cfg->point_mult[p]); ca.shift = cfg->shift; ca.w_lo = w_lo; ca.w_hi = w_hi;
+                hipLaunchKernelGGL(glp_fri_combine_kernel<0>, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, c->stream, ca);
+                GLP_HIPCHK(c, hipGetLastError());
+                koff += batches[b].n_polys;
+                first = false;
+            }
+            if (p > 0) {
+                rc = glp_field_op(c, 0, d_code.u(), d_tmp.u(), d_code.u(), 2 * N);
+                if (rc) return rc;
+            }
         }
     }
 
@@ -400,10 +427,28 @@ extern "C" int glp_fri_prove(glp_ctx* c, const glp_fri_config* cfg, const glp_fr
         }
     }
 
-    uint8_t* blob = (uint8_t*)malloc(P.size() * 8);
-    if (!blob) return GLP_E_NOMEM;
-    memcpy(blob, P.data(), P.size() * 8);   // host is little-endian (x86-64): words are LE u64
-    *proof_out = blob;
-    *proof_len = P.size() * 8;
     return GLP_OK;
+}
+
+uint8_t* glp_words_to_blob(const std::vector<u64>& P, size_t* len) {
+    uint8_t* blob = (uint8_t*)malloc(P.size() * 8 + 8);
+    if (!blob) return nullptr;
+    memcpy(blob, P.data(), P.size() * 8);   // host is little-endian (x86-64): words are LE u64
+    *len = P.size() * 8;
+    return blob;
+}
+
+extern "C" int glp_fri_prove(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batch* batches, uint32_t n_batches,
+                             uint8_t** proof_out, size_t* proof_len) {
+    if (!c) return GLP_E_INVALID;
+    if (!cfg || !batches || n_batches == 0 || !proof_out || !proof_len) { glp_set_err(c, "glp_fri_prove: null argument"); return GLP_E_INVALID; }
+    *proof_out = nullptr; *proof_len = 0;
+    glp_challenger* chp = challenger_new(c);
+    if (!chp) return GLP_E_STATE;
+    std::unique_ptr<glp_challenger> guard(chp);
+    std::vector<u64> P;
+    int rc = glp_fri_prove_impl(c, cfg, batches, n_batches, *chp, P);
+    if (rc) return rc;
+    *proof_out = glp_words_to_blob(P, proof_len);
+    return *proof_out ? GLP_OK : GLP_E_NOMEM;
 }

@@ -1,0 +1,264 @@
+// plonk.hip — prover driver for the build-defined circuit of DESIGN.md §3.6 (SURVEY.md §8a rows
+// a6, a7 and the prover skeleton around them; upstream name recalled, unverified:
+// plonky2::plonk::prover::prove — reference file:line NONE, the mount is empty).
+//
+//   setup : constants (q, c0, c1) and sigma columns -> ifft -> coset LDE -> Merkle  (batch 0)
+//   prove : wires -> batch 1 ; beta, gamma x2 ; Z + partial products (K6) -> batch 2 ;
+//           alpha x2 ; quotient on the LDE domain (K7) -> coefficients -> 8 chunks -> batch 3 ;
+//           FRI opening proof of all four batches at zeta, and of batch 2 at g*zeta.
+// Everything proportional to n runs in kernels; the host runs the transcript and sequencing.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <memory>
+#include <vector>
+#include "glp_ctx.h"
+#include "hash_state.h"
+#include "challenger.h"
+#include "plonk_kernels.cuh"
+
+int glp_ntt_table(glp_ctx* c, int log_N, int inv, const u64** lo, const u64** hi);
+int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batch* batches, uint32_t n_batches, glp_challenger& ch,
+                       std::vector<u64>& P);
+uint8_t* glp_words_to_blob(const std::vector<u64>& P, size_t* len);
+
+namespace {
+struct DBuf {
+    void* p = nullptr;
+    ~DBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    u64* u() const { return (u64*)p; }
+};
+struct Commit {                 // one PolynomialBatch kept on the device
+    DBuf coeffs, lde, dig;
+    std::vector<u64> cap;
+    u32 n_polys = 0;
+};
+}  // namespace
+
+struct glp_plonk_circuit {
+    u32 log_n, W, rate_bits, cap_h;
+    u64 shift;
+    DBuf sigma_vals;            // [W][n] values on the trace domain (K6 input)
+    DBuf ks, inv_xm1;
+    std::vector<u64> h_ks;
+    Commit pre;                 // constants + sigmas
+};
+
+// values [n_polys][n] (device, consumed: turned into coefficients in place) -> Commit
+static int commit_values(glp_ctx* c, u64* d_vals_owned, u32 n_polys, u32 log_n, u32 rb, u32 cap_h, Commit& out) {
+    const u32 log_N = log_n + rb;
+    const u64 N = 1ull << log_N;
+    out.n_polys = n_polys;
+    out.coeffs.p = d_vals_owned;
+    int rc = glp_ntt(c, out.coeffs.u(), log_n, n_polys, 1);
+    if (rc) return rc;
+    GLP_HIPCHK(c, out.lde.alloc((size_t)n_polys * N * 8));
+    rc = glp_lde_coset(c, out.coeffs.u(), out.lde.u(), log_n, rb, n_polys, 7, GLP_NTT_BITREV);
+    if (rc) return rc;
+    const u32 ch = cap_h < log_N ? cap_h : log_N;
+    GLP_HIPCHK(c, out.dig.alloc(8 * 4 * ((2ull << log_N) - (1ull << ch))));
+    out.cap.resize((size_t)4 << ch);
+    return glp_merkle_from_polys(c, out.lde.u(), N, n_polys, log_N, ch, out.dig.u(), out.cap.data());
+}
+
+extern "C" int glp_plonk_setup(glp_ctx* c, uint32_t log_n, uint32_t n_wires, const uint64_t* d_const_vals, const uint64_t* d_sigma_vals,
+                               uint32_t rate_bits, uint32_t cap_height, glp_plonk_circuit** out) {
+    if (!c) return GLP_E_INVALID;
+    if (!out || !d_const_vals || !d_sigma_vals || log_n < 3 || log_n > 24 || n_wires == 0 || n_wires % 8 || n_wires > 128 || rate_bits != 3 ||
+        cap_height > 12) {
+        glp_set_err(c, "glp_plonk_setup: unsupported shape (W %% 8 == 0, W <= 128, rate_bits == 3)");
+        return GLP_E_INVALID;
+    }
+    if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set"); return GLP_E_STATE; }
+    std::unique_ptr<glp_plonk_circuit> ck(new glp_plonk_circuit());
+    ck->log_n = log_n; ck->W = n_wires; ck->rate_bits = rate_bits; ck->cap_h = cap_height; ck->shift = 7;
+    const u64 n = 1ull << log_n;
+    const u32 log_N = log_n + rate_bits;
+    const u64 N = 1ull << log_N;
+    // coset representatives k_j = 7^j
+    ck->h_ks.resize(n_wires);
+    { u64 t = 1; for (u32 j = 0; j < n_wires; j++) { ck->h_ks[j] = t; t = gl_mul(t, 7); } }
+    GLP_HIPCHK(c, ck->ks.alloc(n_wires * 8));
+    GLP_HIPCHK(c, hipMemcpyAsync(ck->ks.p, ck->h_ks.data(), n_wires * 8, hipMemcpyHostToDevice, c->stream));
+    GLP_HIPCHK(c, ck->sigma_vals.alloc((size_t)n_wires * n * 8));
+    GLP_HIPCHK(c, hipMemcpyAsync(ck->sigma_vals.p, d_sigma_vals, (size_t)n_wires * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    // batch 0 = [q, c0, c1, sigma_0 .. sigma_{W-1}]
+    u64* pre_vals = nullptr;
+    GLP_HIPCHK(c, hipMalloc((void**)&pre_vals, (size_t)(3 + n_wires) * n * 8));
+    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals, d_const_vals, (size_t)3 * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals + 3 * n, d_sigma_vals, (size_t)n_wires * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    int rc = commit_values(c, pre_vals, 3 + n_wires, log_n, rate_bits, cap_height, ck->pre);
+    if (rc) return rc;
+    // 1 / (x - 1) on the LDE domain
+    const u64* w_lo = nullptr; const u64* w_hi = nullptr;
+    rc = glp_ntt_table(c, (int)log_N, 0, &w_lo, &w_hi);
+    if (rc) return rc;
+    GLP_HIPCHK(c, ck->inv_xm1.alloc(N * 8));
+    hipLaunchKernelGGL(glp_inv_xm1_kernel<0>, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, c->stream, ck->inv_xm1.u(), log_N, ck->shift,
+                       w_lo, w_hi);
+    GLP_HIPCHK(c, hipGetLastError());
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = ck.release();
+    return GLP_OK;
+}
+
+extern "C" void glp_plonk_free(glp_plonk_circuit* ck) { delete ck; }
+
+extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, uint32_t num_queries, uint32_t pow_bits,
+                               uint8_t** proof_out, size_t* proof_len) {
+    if (!c) return GLP_E_INVALID;
+    if (!ck || !d_wire_vals || !proof_out || !proof_len || num_queries == 0 || num_queries > 256 || pow_bits > 32) {
+        glp_set_err(c, "glp_plonk_prove: bad argument");
+        return GLP_E_INVALID;
+    }
+    *proof_out = nullptr; *proof_len = 0;
+    if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set"); return GLP_E_STATE; }
+    const u32 log_n = ck->log_n, W = ck->W, rb = ck->rate_bits, M = W / GLP_PLONK_CHUNK;
+    const u32 log_N = log_n + rb;
+    const u64 n = 1ull << log_n, N = 1ull << log_N;
+
+    glp_challenger ch;
+    memset(ch.state, 0, sizeof(ch.state));
+    ch.n_in = ch.n_out = 0;
+    ch.consts = c->hash->h_consts;
+    ch.small_mds = c->hash->small_mds;
+    std::vector<u64> P;
+    auto put = [&](u64 v) { P.push_back(v); ch.observe(v % GL_P); };
+    put(0x31304B4C504C4747ull /* "GGLPLK01" */); put(log_n); put(W); put(rb); put(ck->cap_h);
+    for (u64 v : ck->pre.cap) put(v);
+
+    // ---- wires ----------------------------------------------------------------------------
+    Commit wires;
+    {
+        u64* wv = nullptr;
+        GLP_HIPCHK(c, hipMalloc((void**)&wv, (size_t)W * n * 8));
+        GLP_HIPCHK(c, hipMemcpyAsync(wv, d_wire_vals, (size_t)W * n * 8, hipMemcpyDeviceToDevice, c->stream));
+        int rc = commit_values(c, wv, W, log_n, rb, ck->cap_h, wires);
+        if (rc) return rc;
+    }
+    for (u64 v : wires.cap) put(v);
+    u64 beta[GLP_PLONK_NCHAL], gamma[GLP_PLONK_NCHAL], alpha[GLP_PLONK_NCHAL];
+    for (int t = 0; t < GLP_PLONK_NCHAL; t++) beta[t] = ch.challenge();
+    for (int t = 0; t < GLP_PLONK_NCHAL; t++) gamma[t] = ch.challenge();
+
+    // ---- K6: Z and partial products on the trace domain --------------------------------------
+    const u64* wn_lo = nullptr; const u64* wn_hi = nullptr;
+    int rc = glp_ntt_table(c, (int)log_n, 0, &wn_lo, &wn_hi);
+    if (rc) return rc;
+    DBuf qv, rr, bprod;
+    u64* zs_vals = nullptr;
+    GLP_HIPCHK(c, qv.alloc((size_t)GLP_PLONK_NCHAL * M * n * 8));
+    GLP_HIPCHK(c, rr.alloc((size_t)GLP_PLONK_NCHAL * n * 8));
+    GLP_HIPCHK(c, hipMalloc((void**)&zs_vals, (size_t)GLP_PLONK_NCHAL * M * n * 8));
+    Commit zs;
+    zs.coeffs.p = zs_vals;          // owned from here on (freed on any early return)
+    {
+        GlpPermArgs pa;
+        pa.wires = d_wire_vals; pa.sigmas = ck->sigma_vals.u(); pa.ks = ck->ks.u(); pa.log_n = log_n; pa.W = W;
+        for (int t = 0; t < GLP_PLONK_NCHAL; t++) { pa.beta[t] = beta[t]; pa.gamma[t] = gamma[t]; }
+        pa.w_lo = wn_lo; pa.w_hi = wn_hi; pa.qv = qv.u(); pa.rr = rr.u();
+        hipLaunchKernelGGL(glp_perm_quotients_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pa);
+        GLP_HIPCHK(c, hipGetLastError());
+        const u32 nb = (u32)((n + GLP_SCAN_BLOCK - 1) / GLP_SCAN_BLOCK);
+        GLP_HIPCHK(c, bprod.alloc((size_t)GLP_PLONK_NCHAL * nb * 8));
+        hipLaunchKernelGGL(glp_scan_reduce_kernel<0>, dim3(nb, GLP_PLONK_NCHAL), dim3(256), 0, c->stream, rr.u(), n, bprod.u());
+        GLP_HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(glp_scan_blocks_kernel<0>, dim3(GLP_PLONK_NCHAL), dim3(64), 0, c->stream, bprod.u(), nb);
+        GLP_HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(glp_scan_apply_kernel<0>, dim3(nb, GLP_PLONK_NCHAL), dim3(256), 0, c->stream, rr.u(), qv.u(), n, M, bprod.u(), zs_vals);
+        GLP_HIPCHK(c, hipGetLastError());
+    }
+    zs.coeffs.p = nullptr;
+    rc = commit_values(c, zs_vals, GLP_PLONK_NCHAL * M, log_n, rb, ck->cap_h, zs);
+    if (rc) return rc;
+    for (u64 v : zs.cap) put(v);
+    for (int t = 0; t < GLP_PLONK_NCHAL; t++) alpha[t] = ch.challenge();
+
+    // ---- K7: quotient on the LDE domain --------------------------------------------------------
+    const u32 n_con = 1 + 3 * M;
+    std::vector<u64> apow((size_t)GLP_PLONK_NCHAL * n_con);
+    for (int t = 0; t < GLP_PLONK_NCHAL; t++) { u64 x = 1; for (u32 k = 0; k < n_con; k++) { apow[(size_t)t * n_con + k] = x; x = gl_mul(x, alpha[t]); } }
+    DBuf d_apow, quot_rev;
+    GLP_HIPCHK(c, d_apow.alloc(apow.size() * 8));
+    GLP_HIPCHK(c, hipMemcpyAsync(d_apow.p, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, c->stream));
+    GLP_HIPCHK(c, quot_rev.alloc((size_t)GLP_PLONK_NCHAL * N * 8));
+    const u64* wN_lo = nullptr; const u64* wN_hi = nullptr;
+    rc = glp_ntt_table(c, (int)log_N, 0, &wN_lo, &wN_hi);
+    if (rc) return rc;
+    {
+        GlpQuotientArgs qa;
+        qa.consts = ck->pre.lde.u(); qa.sigmas = ck->pre.lde.u() + 3 * N; qa.wires = wires.lde.u(); qa.zs = zs.lde.u(); qa.ks = ck->ks.u();
+        qa.log_n = log_n; qa.rate_bits = rb; qa.W = W;
+        for (int t = 0; t < GLP_PLONK_NCHAL; t++) { qa.beta[t] = beta[t]; qa.gamma[t] = gamma[t]; }
+        qa.alpha_pow = d_apow.u(); qa.w_lo = wN_lo; qa.w_hi = wN_hi; qa.shift = ck->shift;
+        // x^n for natural index e: shift^n * w_N^(e n) = shift^n * w_{2^rb}^(e mod 2^rb)
+        const u64 sn = gl_pow(ck->shift, n), wr = gl_root_of_unity(rb);
+        for (u32 k = 0; k < (1u << rb); k++) qa.zh_inv[k] = gl_inv(gl_sub(gl_mul(sn, gl_pow(wr, k)), 1));
+        qa.n_inv = gl_inv(n % GL_P);
+        qa.inv_xm1 = ck->inv_xm1.u();
+        qa.out = quot_rev.u();
+        hipLaunchKernelGGL(glp_quotient_kernel<0>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa);
+        GLP_HIPCHK(c, hipGetLastError());
+    }
+    // evaluations (bit-reversed, coset) -> coefficients: un-bit-reverse, inverse NTT, unshift
+    u64* quot_nat = nullptr;
+    GLP_HIPCHK(c, hipMalloc((void**)&quot_nat, (size_t)GLP_PLONK_NCHAL * N * 8));
+    Commit quot;
+    quot.coeffs.p = quot_nat;
+    hipLaunchKernelGGL(glp_bitrev_permute_kernel<0>, dim3((unsigned)(((u64)GLP_PLONK_NCHAL * N + 255) / 256)), dim3(256), 0, c->stream,
+                       quot_rev.u(), quot_nat, log_N, GLP_PLONK_NCHAL);
+    GLP_HIPCHK(c, hipGetLastError());
+    rc = glp_ntt(c, quot_nat, log_N, GLP_PLONK_NCHAL, 1);
+    if (rc) return rc;
+    {
+        const u64 sinv = gl_inv(ck->shift);
+        std::vector<u64> lo(4096), hi(N > 4096 ? (N >> 12) : 1);
+        u64 t = 1;
+        for (u32 k = 0; k < 4096; k++) { lo[k] = t; t = gl_mul(t, sinv); }
+        const u64 s4096 = t;
+        t = 1;
+        for (size_t k = 0; k < hi.size(); k++) { hi[k] = t; t = gl_mul(t, s4096); }
+        DBuf dlo, dhi;
+        GLP_HIPCHK(c, dlo.alloc(lo.size() * 8));
+        GLP_HIPCHK(c, dhi.alloc(hi.size() * 8));
+        GLP_HIPCHK(c, hipMemcpyAsync(dlo.p, lo.data(), lo.size() * 8, hipMemcpyHostToDevice, c->stream));
+        GLP_HIPCHK(c, hipMemcpyAsync(dhi.p, hi.data(), hi.size() * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(glp_scale_pow_kernel<0>, dim3(4096), dim3(256), 0, c->stream, quot_nat, log_N, GLP_PLONK_NCHAL, dlo.u(),
+                           N > 4096 ? dhi.u() : (const u64*)nullptr);
+        GLP_HIPCHK(c, hipGetLastError());
+        GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    // each quotient has 8n coefficients = 8 chunks of n: [NCHAL][8][n] is already a dense
+    // batch of 16 coefficient-form polynomials
+    {
+        const u32 nq = GLP_PLONK_NCHAL << rb;
+        quot.n_polys = nq;
+        GLP_HIPCHK(c, quot.lde.alloc((size_t)nq * N * 8));
+        rc = glp_lde_coset(c, quot.coeffs.u(), quot.lde.u(), log_n, rb, nq, 7, GLP_NTT_BITREV);
+        if (rc) return rc;
+        const u32 chh = ck->cap_h < log_N ? ck->cap_h : log_N;
+        GLP_HIPCHK(c, quot.dig.alloc(8 * 4 * ((2ull << log_N) - (1ull << chh))));
+        quot.cap.resize((size_t)4 << chh);
+        rc = glp_merkle_from_polys(c, quot.lde.u(), N, nq, log_N, chh, quot.dig.u(), quot.cap.data());
+        if (rc) return rc;
+    }
+    for (u64 v : quot.cap) put(v);
+
+    // ---- openings: everything at zeta, the Z batch also at g*zeta --------------------------------
+    glp_fri_config fc;
+    memset(&fc, 0, sizeof(fc));
+    fc.log_n = log_n; fc.rate_bits = rb; fc.cap_height = ck->cap_h; fc.arity_bits = 4; fc.final_poly_bits = 5;
+    fc.num_queries = num_queries; fc.pow_bits = pow_bits; fc.shift = ck->shift;
+    fc.n_points = 2; fc.point_mult[0] = 1; fc.point_mult[1] = gl_root_of_unity(log_n);
+    glp_fri_batch fb[4];
+    Commit* cs[4] = {&ck->pre, &wires, &zs, &quot};
+    for (int b = 0; b < 4; b++) {
+        fb[b].d_coeffs = cs[b]->coeffs.u(); fb[b].d_lde = cs[b]->lde.u(); fb[b].d_digests = cs[b]->dig.u();
+        fb[b].h_cap = cs[b]->cap.data(); fb[b].n_polys = cs[b]->n_polys; fb[b].open_mask = (b == 2) ? 3u : 1u;
+    }
+    rc = glp_fri_prove_impl(c, &fc, fb, 4, ch, P);
+    if (rc) return rc;
+    *proof_out = glp_words_to_blob(P, proof_len);
+    return *proof_out ? GLP_OK : GLP_E_NOMEM;
+}

@@ -1,0 +1,278 @@
+// plonk_kernels.cuh — permutation-argument products (Z and partial products) and quotient
+// evaluation for the build-defined circuit of DESIGN.md §3.6 (SURVEY.md §8a rows a6, a7;
+// upstream names recalled, unverified: plonky2::plonk::prover::compute_partial_products_and_z_polys,
+// compute_quotient_polys / vanishing_poly::eval_vanishing_poly_base_batch — reference
+// file:line NONE, the mount is empty; the gate set and constraint order here are build-defined).
+//
+// Circuit: n = 2^k rows, W wire columns (all routed, W % 8 == 0).  One gate type, applied to
+// every group of 4 wires (x, y, z, w) of a row:  q * (c0*x*y + c1*z - w) = 0  with per-row
+// constants q (selector), c0, c1.  Copy constraints via the plonky2-style permutation argument
+// with chunks of 8 wires and num_challenges = 2:
+//   num_j = w_j + beta*k_j*x + gamma,   den_j = w_j + beta*sigma_j + gamma
+//   Z(g x) = Z(x) * prod_c q_c(x),  q_c = prod_{j in chunk c} num_j / den_j,
+//   partial products pi_c = Z * q_0 ... q_c  (c < M-1),  M = W/8 chunks.
+// Plain HIP C++ without AMD builtins (tests/emu runs these bodies on the CPU).
+#pragma once
+#include "gl_field.cuh"
+
+#define GLP_PLONK_CHUNK 8
+#define GLP_PLONK_NCHAL 2
+
+// ---- K6a: per-row chunk quotients ------------------------------------------------------
+// wires, sigmas: [W][n] values on the trace domain (natural order).  ks[j] = k_j.
+// qv: [NCHAL][M][n] chunk quotients, rr: [NCHAL][n] row ratios prod_c q_c.
+// xs = table of w_n^i (two-level, forward) to get x = w^i.
+struct GlpPermArgs {
+    const u64* wires; const u64* sigmas; const u64* ks;
+    u32 log_n; u32 W;
+    u64 beta[GLP_PLONK_NCHAL], gamma[GLP_PLONK_NCHAL];
+    const u64* w_lo; const u64* w_hi;
+    u64* qv; u64* rr;
+};
+// One field inversion per (row, challenge): the M chunk denominators are inverted together
+// (prefix products parked in qv, which is overwritten by the quotients on the way back).
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_perm_quotients_kernel(GlpPermArgs a) {
+    const u64 n = 1ull << a.log_n;
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 M = a.W / GLP_PLONK_CHUNK;
+    u64 x = a.w_lo[i & 4095u];
+    if (a.w_hi) x = gl_mul(x, a.w_hi[i >> 12]);
+    for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
+        const u64 bx = gl_mul(a.beta[t], x);
+        auto chunk = [&](u32 c, u64& num, u64& den) {
+            num = 1; den = 1;
+            glp_static_for<0, GLP_PLONK_CHUNK>([&](auto j_) {
+                constexpr int jj = decltype(j_)::value;
+                const u32 j = c * GLP_PLONK_CHUNK + jj;
+                const u64 wg = gl_add(a.wires[(u64)j * n + i], a.gamma[t]);
+                num = gl_mul(num, gl_add(wg, gl_mul(bx, a.ks[j])));
+                den = gl_mul(den, gl_add(wg, gl_mul(a.beta[t], a.sigmas[(u64)j * n + i])));
+            });
+        };
+        u64 run = 1;                                   // prefix products of the denominators
+        for (u32 c = 0; c < M; c++) {
+            u64 num, den;
+            chunk(c, num, den);
+            run = gl_mul(run, den);
+            a.qv[((u64)t * M + c) * n + i] = run;
+        }
+        u64 inv = gl_inv(run);                          // != 0 except with negligible probability
+        u64 ratio = 1;
+        for (u32 c = M; c-- > 0;) {
+            u64 num, den;
+            chunk(c, num, den);
+            const u64 before = c ? a.qv[((u64)t * M + c - 1) * n + i] : 1ull;
+            const u64 q = gl_mul(num, gl_mul(inv, before));   // num_c / den_c
+            inv = gl_mul(inv, den);
+            a.qv[((u64)t * M + c) * n + i] = q;
+            ratio = gl_mul(ratio, q);
+        }
+        a.rr[(u64)t * n + i] = ratio;
+    }
+}
+
+// ---- K6b: exclusive prefix product over rows ------------------------------------------------
+// Three launches: (1) every block reduces its 1024 rows to one product; (2) one block scans
+// the block products (<= 1024 of them per challenge, i.e. n <= 2^20 per launch of this
+// simple form; larger n loops on the host); (3) every block rescans its rows with its prefix.
+#define GLP_SCAN_BLOCK 1024u
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_scan_reduce_kernel(const u64* __restrict__ rr, u64 n, u64* __restrict__ block_prod) {
+    __shared__ u64 sh[256];
+    const u64 base = (u64)blockIdx.x * GLP_SCAN_BLOCK;     // blockIdx.y = challenge
+    const u64* src = rr + (u64)blockIdx.y * n;
+    u64 p = 1;
+    for (u32 k = 0; k < GLP_SCAN_BLOCK / 256; k++) {
+        const u64 idx = base + (u64)threadIdx.x * (GLP_SCAN_BLOCK / 256) + k;
+        if (idx < n) p = gl_mul(p, src[idx]);
+    }
+    sh[threadIdx.x] = p;
+    __syncthreads();
+    for (u32 s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] = gl_mul(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_prod[(u64)blockIdx.y * gridDim.x + blockIdx.x] = sh[0];
+}
+// one block per challenge: exclusive scan of nb block products in place (serial over 256-chunks)
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_scan_blocks_kernel(u64* __restrict__ block_prod, u32 nb) {
+    if (threadIdx.x != 0) return;
+    u64* bp = block_prod + (u64)blockIdx.x * nb;
+    u64 run = 1;
+    for (u32 b = 0; b < nb; b++) { const u64 v = bp[b]; bp[b] = run; run = gl_mul(run, v); }
+}
+// Z[t][i] = prefix(block) * prod_{i' in block, i' < i} rr[t][i'];  each thread handles 4 rows.
+// Also writes the partial products pi_c = Z * q_0..q_c for c < M-1 into zs[t][1+c][i].
+// zs layout: [NCHAL][M][n]  (poly 0 = Z, poly 1+c = pi_c).
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_scan_apply_kernel(const u64* __restrict__ rr, const u64* __restrict__ qv, u64 n, u32 M,
+                                                             const u64* __restrict__ block_prefix, u64* __restrict__ zs) {
+    __shared__ u64 sh[256];
+    const u32 t = blockIdx.y;
+    const u64 base = (u64)blockIdx.x * GLP_SCAN_BLOCK + (u64)threadIdx.x * 4;
+    const u64* src = rr + (u64)t * n;
+    u64 v[4], p = 1;
+    for (u32 k = 0; k < 4; k++) { v[k] = (base + k < n) ? src[base + k] : 1; }
+    const u64 mine = gl_mul(gl_mul(v[0], v[1]), gl_mul(v[2], v[3]));
+    // inclusive scan of the 256 thread products (Hillis-Steele in LDS)
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (u32 off = 1; off < 256; off <<= 1) {
+        u64 add = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 1;
+        __syncthreads();
+        sh[threadIdx.x] = gl_mul(sh[threadIdx.x], add);
+        __syncthreads();
+    }
+    const u64 excl = (threadIdx.x == 0) ? 1 : sh[threadIdx.x - 1];
+    p = gl_mul(block_prefix[(u64)t * gridDim.x + blockIdx.x], excl);
+    for (u32 k = 0; k < 4; k++) {
+        const u64 i = base + k;
+        if (i < n) {
+            zs[((u64)t * M + 0) * n + i] = p;
+            u64 run = p;
+            for (u32 c = 0; c + 1 < M; c++) {
+                run = gl_mul(run, qv[((u64)t * M + c) * n + i]);
+                zs[((u64)t * M + 1 + c) * n + i] = run;
+            }
+        }
+        p = gl_mul(p, v[k]);
+    }
+}
+
+// ---- K7: quotient evaluation on the LDE domain ------------------------------------------------
+// All inputs are LDE values, polynomial-major [.][N], bit-reversed index order, N = n << rate_bits.
+// consts: [3][N] = (q, c0, c1); sigmas: [W][N]; wires: [W][N]; zs: [NCHAL*M][N].
+// Constraint order (index into alpha powers), per challenge t:
+//   0            L_1(x) * (Z(x) - 1)
+//   1 + 3c       prev_c * prod(num) - next_c * prod(den)            chunk c of 8 wires
+//   2 + 3c, 3+3c the two arithmetic gates of chunk c (wires 8c..8c+3 and 8c+4..8c+7)
+// out[t][i] = (sum alpha_t^idx * constraint_idx) / (x^n - 1).
+struct GlpQuotientArgs {
+    const u64* consts; const u64* sigmas; const u64* wires; const u64* zs; const u64* ks;
+    u32 log_n; u32 rate_bits; u32 W;
+    u64 beta[GLP_PLONK_NCHAL], gamma[GLP_PLONK_NCHAL];
+    const u64* alpha_pow;          // [NCHAL][1 + 3M]
+    const u64* w_lo; const u64* w_hi;   // forward table of w_N
+    u64 shift;                     // coset shift of the LDE domain
+    u64 zh_inv[64];                // 1 / (x^n - 1) for the 2^rate_bits values x^n takes, indexed by (natural index) mod 2^rate_bits
+    u64 n_inv;                     // 1 / n
+    const u64* inv_xm1;            // [N] 1 / (x_i - 1), bit-reversed order (built once per domain)
+    u64* out;                      // [NCHAL][N]
+};
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
+    const u32 log_N = a.log_n + a.rate_bits;
+    const u64 N = 1ull << log_N;
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const u32 M = a.W / GLP_PLONK_CHUNK;
+    u64 e = 0;                                   // natural index of this point
+    for (u32 b = 0; b < log_N; b++) e |= ((i >> b) & 1ull) << (log_N - 1 - b);
+    u64 x = a.w_lo[e & 4095u];
+    if (a.w_hi) x = gl_mul(x, a.w_hi[e >> 12]);
+    x = gl_mul(x, a.shift);
+    // the "next row" point g*x is natural index e + 2^rate_bits (mod N) -> its bit-reversed position
+    const u64 en = (e + (1ull << a.rate_bits)) & (N - 1);
+    u64 inext = 0;
+    for (u32 b = 0; b < log_N; b++) inext |= ((en >> b) & 1ull) << (log_N - 1 - b);
+    const u64 zhi = a.zh_inv[e & ((1ull << a.rate_bits) - 1)];
+    // L_1(x) * (Z - 1) / (x^n - 1) = (Z - 1) / (n (x - 1)): the vanishing factor cancels
+    const u64 l1_over_zh = gl_mul(a.n_inv, a.inv_xm1[i]);
+    const u64 q = a.consts[i], c0 = a.consts[N + i], c1 = a.consts[2 * N + i];
+    u64 acc[GLP_PLONK_NCHAL], prev[GLP_PLONK_NCHAL], bx[GLP_PLONK_NCHAL];
+    for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
+        const u64 z = a.zs[((u64)t * M) * N + i];
+        acc[t] = 0;
+        prev[t] = z;
+        bx[t] = gl_mul(a.beta[t], x);
+    }
+    for (u32 c = 0; c < M; c++) {
+        u64 w[GLP_PLONK_CHUNK], sg[GLP_PLONK_CHUNK], kk[GLP_PLONK_CHUNK];
+        glp_static_for<0, GLP_PLONK_CHUNK>([&](auto j_) {
+            constexpr int jj = decltype(j_)::value;
+            const u64 j = (u64)c * GLP_PLONK_CHUNK + jj;
+            w[jj] = a.wires[j * N + i];
+            sg[jj] = a.sigmas[j * N + i];
+            kk[jj] = a.ks[j];
+        });
+        // the two arithmetic gates of this chunk (shared by both challenges up to alpha)
+        const u64 g0 = gl_mul(q, gl_sub(gl_add(gl_mul(c0, gl_mul(w[0], w[1])), gl_mul(c1, w[2])), w[3]));
+        const u64 g1 = gl_mul(q, gl_sub(gl_add(gl_mul(c0, gl_mul(w[4], w[5])), gl_mul(c1, w[6])), w[7]));
+        for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
+            u64 num = 1, den = 1;
+            glp_static_for<0, GLP_PLONK_CHUNK>([&](auto j_) {
+                constexpr int jj = decltype(j_)::value;
+                const u64 wg = gl_add(w[jj], a.gamma[t]);
+                num = gl_mul(num, gl_add(wg, gl_mul(bx[t], kk[jj])));
+                den = gl_mul(den, gl_add(wg, gl_mul(a.beta[t], sg[jj])));
+            });
+            const u64 next = (c + 1 < M) ? a.zs[((u64)t * M + 1 + c) * N + i] : a.zs[((u64)t * M) * N + inext];
+            const u64 perm = gl_sub(gl_mul(prev[t], num), gl_mul(next, den));
+            const u64* ap = a.alpha_pow + (u64)t * (1 + 3 * M) + 1 + 3 * c;
+            acc[t] = gl_add(acc[t], gl_mul(ap[0], perm));
+            acc[t] = gl_add(acc[t], gl_mul(ap[1], g0));
+            acc[t] = gl_add(acc[t], gl_mul(ap[2], g1));
+            prev[t] = next;
+        }
+    }
+    for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
+        const u64 z = a.zs[((u64)t * M) * N + i];
+        a.out[(u64)t * N + i] = gl_add(gl_mul(acc[t], zhi), gl_mul(l1_over_zh, gl_sub(z, 1)));   // alpha^0 = 1
+    }
+}
+
+// inv[i] = 1 / (x_i - 1) over the LDE domain (bit-reversed order), 4 points per work-item share
+// one inversion.  Built once per (log_N, shift).
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_inv_xm1_kernel(u64* __restrict__ inv, u32 log_N, u64 shift, const u64* __restrict__ w_lo,
+                                                          const u64* __restrict__ w_hi) {
+    const u64 N = 1ull << log_N;
+    const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= N) return;
+    u64 d[4];
+    glp_static_for<0, 4>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        const u64 i = i0 + k;
+        u64 e = 0;
+        for (u32 b = 0; b < log_N; b++) e |= ((i >> b) & 1ull) << (log_N - 1 - b);
+        u64 x = w_lo[e & 4095u];
+        if (w_hi) x = gl_mul(x, w_hi[e >> 12]);
+        d[k] = gl_sub(gl_mul(x, shift), 1);
+    });
+    const u64 p01 = gl_mul(d[0], d[1]), p012 = gl_mul(p01, d[2]);
+    u64 t = gl_inv(gl_mul(p012, d[3]));
+    inv[i0 + 3] = gl_mul(t, p012); t = gl_mul(t, d[3]);
+    inv[i0 + 2] = gl_mul(t, p01); t = gl_mul(t, d[2]);
+    inv[i0 + 1] = gl_mul(t, d[0]);
+    inv[i0 + 0] = gl_mul(t, d[1]);
+}
+
+// out[rev(i)] = in[i] per polynomial (bit-reversed <-> natural order)
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_bitrev_permute_kernel(const u64* __restrict__ in, u64* __restrict__ out, u32 log_n,
+                                                                 u32 batch) {
+    const u64 n = 1ull << log_n;
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ((u64)batch << log_n)) return;
+    const u64 b = g >> log_n, i = g & (n - 1);
+    u64 r = 0;
+    for (u32 k = 0; k < log_n; k++) r |= ((i >> k) & 1ull) << (log_n - 1 - k);
+    out[b * n + r] = in[g];
+}
+
+// data[b][j] *= s^j  (s^j = lo[j & 4095] * hi[j >> 12])
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_scale_pow_kernel(u64* __restrict__ data, u32 log_n, u32 batch, const u64* __restrict__ lo,
+                                                            const u64* __restrict__ hi) {
+    const u64 n = 1ull << log_n;
+    const u64 total = (u64)batch << log_n;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
+        const u64 j = g & (n - 1);
+        u64 s = lo[j & 4095u];
+        if (hi) s = gl_mul(s, hi[j >> 12]);
+        data[g] = gl_mul(data[g], s);
+    }
+}

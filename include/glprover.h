@@ -138,6 +138,8 @@ typedef struct {
     uint32_t num_queries;
     uint32_t pow_bits;
     uint64_t shift;            /* coset shift of the LDE domain (7) */
+    uint32_t n_points;         /* 1..4 opening points z_p = zeta * point_mult[p] (zeta from the transcript) */
+    uint64_t point_mult[4];    /* base-field multipliers; {1} for a single point, {1, w_n} to also open the next row */
 } glp_fri_config;
 typedef struct {               /* one committed batch, as produced by ifft -> glp_lde_coset(BITREV) -> glp_merkle_from_polys */
     const uint64_t* d_coeffs;  /* [n_polys][2^log_n], dense */
@@ -145,12 +147,29 @@ typedef struct {               /* one committed batch, as produced by ifft -> gl
     const uint64_t* d_digests; /* Merkle digests of that LDE (layout of glp_merkle) */
     const uint64_t* h_cap;     /* its cap: 4 << min(cap_height, log_n+rate_bits) words (host) */
     uint32_t n_polys;
+    uint32_t open_mask;        /* bit p set: every polynomial of the batch is opened at point p */
 } glp_fri_batch;
-/* proves the openings of every polynomial of every batch at one transcript-derived point.
+/* proves the openings of the batches at the transcript-derived point(s) selected by open_mask.
  * *proof is malloc'd by the library (little-endian u64 words), free with glp_free_host. */
 int glp_fri_prove(glp_ctx* ctx, const glp_fri_config* cfg, const glp_fri_batch* batches, uint32_t n_batches,
                   uint8_t** proof, size_t* proof_len);
 void glp_free_host(void* p);
+
+/* ---- prover for the build-defined circuit (rows a6, a7 + driver; upstream names recalled:
+ *      plonk::prover::prove, compute_partial_products_and_z_polys, compute_quotient_polys).
+ * Circuit: 2^log_n rows, n_wires columns (all routed, multiple of 8, <= 128);
+ * every group of 4 wires (x, y, z, w) of a row satisfies q*(c0*x*y + c1*z - w) = 0; copy
+ * constraints through sigma.  d_const_vals: [3][n] = (q, c0, c1) row values; d_sigma_vals:
+ * [n_wires][n] with sigma_j(row i) = k_{j'} * w_n^{i'} for the cell (j', i') that (j, i) maps to,
+ * k_j = 7^j.  rate_bits must be 3. */
+typedef struct glp_plonk_circuit glp_plonk_circuit;
+int glp_plonk_setup(glp_ctx* ctx, uint32_t log_n, uint32_t n_wires, const uint64_t* d_const_vals, const uint64_t* d_sigma_vals,
+                    uint32_t rate_bits, uint32_t cap_height, glp_plonk_circuit** out);
+void glp_plonk_free(glp_plonk_circuit* ck);
+/* d_wire_vals: [n_wires][n] witness values.  Proof = header, four caps, then the FRI opening
+ * proof (all batches at zeta, the Z batch also at w_n*zeta).  Free with glp_free_host. */
+int glp_plonk_prove(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, uint32_t num_queries, uint32_t pow_bits,
+                    uint8_t** proof, size_t* proof_len);
 
 /* ---- witness generation (rows a9; upstream names recalled: curta SHA-256/SHA-512 chips) */
 /* n_msgs messages, each already padded to blocks_per_msg 64-byte blocks, [n_msgs][blocks*64].

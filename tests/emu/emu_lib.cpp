@@ -210,3 +210,65 @@ extern "C" int emu_pow(const u64* seed, u64 base, u64 count, u32 pow_bits, const
     else glp_emu_launch((unsigned)((count + 63) / 64), 64, 0, [&] { glp_pow_kernel<false>(seed, base, count, pow_bits, found, k); });
     return 0;
 }
+
+// ---- PLONK kernels (rows a6, a7) under emulation ------------------------------------------
+#include "../../0-kno-blobstreamx_amd/csrc/plonk_kernels.cuh"
+
+extern "C" int emu_plonk_zs(const u64* wires, const u64* sigmas, u32 log_n, u32 W, const u64* beta, const u64* gamma, u64* zs) {
+    const u64 n = 1ull << log_n;
+    const u32 M = W / GLP_PLONK_CHUNK;
+    std::vector<u64> lo(glp_table_lo_len(log_n)), hi(glp_table_hi_len(log_n) ? glp_table_hi_len(log_n) : 1), ks(W);
+    glp_fill_table(log_n, 0, lo.data(), hi.data());
+    { u64 t = 1; for (u32 j = 0; j < W; j++) { ks[j] = t; t = gl_mul(t, 7); } }
+    std::vector<u64> qv((size_t)GLP_PLONK_NCHAL * M * n), rr((size_t)GLP_PLONK_NCHAL * n);
+    GlpPermArgs pa;
+    pa.wires = wires; pa.sigmas = sigmas; pa.ks = ks.data(); pa.log_n = log_n; pa.W = W;
+    for (int t = 0; t < GLP_PLONK_NCHAL; t++) { pa.beta[t] = beta[t]; pa.gamma[t] = gamma[t]; }
+    pa.w_lo = lo.data(); pa.w_hi = glp_table_hi_len(log_n) ? hi.data() : nullptr; pa.qv = qv.data(); pa.rr = rr.data();
+    glp_emu_launch((unsigned)((n + 63) / 64), 64, 0, [&] { glp_perm_quotients_kernel<0>(pa); });
+    const u32 nb = (u32)((n + GLP_SCAN_BLOCK - 1) / GLP_SCAN_BLOCK);
+    std::vector<u64> bprod((size_t)GLP_PLONK_NCHAL * nb);
+    // 2-D grids: emulate blockIdx.y by an outer loop
+    for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
+        glp_emu_launch(nb, 256, 0, [&] { blockIdx.y = t; gridDim.y = GLP_PLONK_NCHAL; glp_scan_reduce_kernel<0>(rr.data(), n, bprod.data()); });
+    }
+    glp_emu_launch(GLP_PLONK_NCHAL, 64, 0, [&] { glp_scan_blocks_kernel<0>(bprod.data(), nb); });
+    for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
+        glp_emu_launch(nb, 256, 0, [&] { blockIdx.y = t; gridDim.y = GLP_PLONK_NCHAL; glp_scan_apply_kernel<0>(rr.data(), qv.data(), n, M, bprod.data(), zs); });
+    }
+    return 0;
+}
+
+extern "C" int emu_plonk_quotient(const u64* consts, const u64* sigmas, const u64* wires, const u64* zs, u32 log_n, u32 rb, u32 W,
+                                  const u64* beta, const u64* gamma, const u64* alpha, u64* out) {
+    const u32 log_N = log_n + rb, M = W / GLP_PLONK_CHUNK, n_con = 1 + 3 * M;
+    const u64 n = 1ull << log_n, N = 1ull << log_N;
+    std::vector<u64> lo(glp_table_lo_len(log_N)), hi(glp_table_hi_len(log_N) ? glp_table_hi_len(log_N) : 1), ks(W), inv(N);
+    glp_fill_table(log_N, 0, lo.data(), hi.data());
+    const u64* hip = glp_table_hi_len(log_N) ? hi.data() : nullptr;
+    { u64 t = 1; for (u32 j = 0; j < W; j++) { ks[j] = t; t = gl_mul(t, 7); } }
+    glp_emu_launch((unsigned)((N / 4 + 63) / 64), 64, 0, [&] { glp_inv_xm1_kernel<0>(inv.data(), log_N, 7, lo.data(), hip); });
+    std::vector<u64> apow((size_t)GLP_PLONK_NCHAL * n_con);
+    for (int t = 0; t < GLP_PLONK_NCHAL; t++) { u64 x = 1; for (u32 k = 0; k < n_con; k++) { apow[(size_t)t * n_con + k] = x; x = gl_mul(x, alpha[t]); } }
+    GlpQuotientArgs qa;
+    qa.consts = consts; qa.sigmas = sigmas; qa.wires = wires; qa.zs = zs; qa.ks = ks.data(); qa.log_n = log_n; qa.rate_bits = rb; qa.W = W;
+    for (int t = 0; t < GLP_PLONK_NCHAL; t++) { qa.beta[t] = beta[t]; qa.gamma[t] = gamma[t]; }
+    qa.alpha_pow = apow.data(); qa.w_lo = lo.data(); qa.w_hi = hip; qa.shift = 7;
+    const u64 sn = gl_pow(7, n), wr = gl_root_of_unity(rb);
+    for (u32 k = 0; k < (1u << rb); k++) qa.zh_inv[k] = gl_inv(gl_sub(gl_mul(sn, gl_pow(wr, k)), 1));
+    qa.n_inv = gl_inv(n % GL_P); qa.inv_xm1 = inv.data(); qa.out = out;
+    glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<0>(qa); });
+    return 0;
+}
+
+extern "C" int emu_bitrev_scale(const u64* in, u64* out, u32 log_n, u32 batch, u64 s) {
+    const u64 n = 1ull << log_n;
+    glp_emu_launch((unsigned)((((u64)batch << log_n) + 63) / 64), 64, 0, [&] { glp_bitrev_permute_kernel<0>(in, out, log_n, batch); });
+    std::vector<u64> lo(4096), hi(n > 4096 ? (n >> 12) : 1);
+    u64 t = 1;
+    for (u32 k = 0; k < 4096; k++) { lo[k] = t; t = gl_mul(t, s); }
+    const u64 s4096 = t; t = 1;
+    for (size_t k = 0; k < hi.size(); k++) { hi[k] = t; t = gl_mul(t, s4096); }
+    glp_emu_launch(8, 64, 0, [&] { glp_scale_pow_kernel<0>(out, log_n, batch, lo.data(), n > 4096 ? hi.data() : nullptr); });
+    return 0;
+}

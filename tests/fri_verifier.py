@@ -8,7 +8,7 @@ import numpy as np
 
 P = 2**64 - 2**32 + 1
 W = 7
-TAG = 0x31304952464C4747
+TAG = 0x32304952464C4747
 u64p = ctypes.POINTER(ctypes.c_uint64)
 
 
@@ -111,9 +111,11 @@ def merkle_check(h, leaf_digest, index, path, cap):
         raise VerifyError("Merkle path does not lead to the cap")
 
 
-def parse_and_verify(proof_bytes, oracle):
-    words = np.frombuffer(proof_bytes, dtype="<u8")
-    pos = 0
+def parse_and_verify(proof_bytes, oracle, challenger=None, words=None, pos=0, allow_trailing=False):
+    """verify a stand-alone FRI proof, or (challenger/words/pos given) the FRI part embedded in a
+    larger proof, continuing that proof's transcript"""
+    if words is None:
+        words = np.frombuffer(proof_bytes, dtype="<u8")
 
     def take(n=1):
         nonlocal pos
@@ -124,12 +126,18 @@ def parse_and_verify(proof_bytes, oracle):
         return out
 
     h = Hasher(oracle)
-    ch = Challenger(h)
-    tag, log_n, rb, cap0, a, fb, nq, pow_bits, shift, nb = take(10)
+    ch = challenger if challenger is not None else Challenger(h)
+    tag, log_n, rb, cap0, a, fb, nq, pow_bits, shift, nb, n_pts = take(11)
     if tag != TAG:
         raise VerifyError("bad tag")
-    n_polys = take(nb)
-    for w in [tag, log_n, rb, cap0, a, fb, nq, pow_bits, shift, nb] + n_polys:
+    if not (1 <= n_pts <= 4) or nb == 0 or nb > 64:
+        raise VerifyError("bad header")
+    mults = take(n_pts)
+    pm = take(2 * nb)
+    n_polys, masks = pm[0::2], pm[1::2]
+    if any(m == 0 or (m >> n_pts) for m in masks) or not any(m & 1 for m in masks):
+        raise VerifyError("bad open masks")
+    for w in [tag, log_n, rb, cap0, a, fb, nq, pow_bits, shift, nb, n_pts] + mults + pm:
         ch.observe(w)
     log_N = log_n + rb
     N = 1 << log_N
@@ -146,7 +154,9 @@ def parse_and_verify(proof_bytes, oracle):
             ch.observe(v)
         caps.append([c[4 * i:4 * i + 4] for i in range(1 << cap0)])
     zeta = ch.ext_challenge()
-    total = sum(n_polys)
+    # openings in (point, batch, polynomial) order
+    order = [(p, b) for p in range(n_pts) for b in range(nb) if (masks[b] >> p) & 1]
+    total = sum(n_polys[b] for _, b in order)
     op = take(2 * total)
     if any(v >= P for v in op):
         raise VerifyError("non-canonical opening")
@@ -157,9 +167,13 @@ def parse_and_verify(proof_bytes, oracle):
     apow = [(1, 0)]
     for _ in range(total - 1):
         apow.append(emul(apow[-1], alpha))
-    Y = (0, 0)
-    for k in range(total):
-        Y = eadd(Y, emul(apow[k], openings[k]))
+    zs_pt = [escale(zeta, m) for m in mults]
+    Ys = [(0, 0)] * n_pts
+    kk = 0
+    for p, b in order:
+        for _ in range(n_polys[b]):
+            Ys[p] = eadd(Ys[p], emul(apow[kk], openings[kk]))
+            kk += 1
     layer_caps, betas, layer_log, layer_caph = [], [], [], []
     log_len = log_N
     for _ in range(L):
@@ -192,17 +206,23 @@ def parse_and_verify(proof_bytes, oracle):
         if idx != idxs[q]:
             raise VerifyError("query index does not match the transcript")
         x = shift * pow(w_N, rev(idx, log_N), P) % P
-        acc = (0, 0)
-        k = 0
+        leaves = []
         for b in range(nb):
             leaf = take(n_polys[b])
             path = take(4 * (log_N - cap0))
             path = [path[4 * i:4 * i + 4] for i in range(log_N - cap0)]
             merkle_check(h, h.hash_or_noop(leaf), idx, path, caps[b])
-            for v in leaf:
-                acc = eadd(acc, escale(apow[k], v))
+            leaves.append(leaf)
+        cur = (0, 0)
+        k = 0
+        accs = [(0, 0)] * n_pts
+        for p, b in order:
+            for v in leaves[b]:
+                accs[p] = eadd(accs[p], escale(apow[k], v))
                 k += 1
-        cur = emul(esub(acc, Y), einv(esub((x, 0), zeta)))
+        for p in range(n_pts):
+            if any(pp == p for pp, _ in order):
+                cur = eadd(cur, emul(esub(accs[p], Ys[p]), einv(esub((x, 0), zs_pt[p]))))
         sh = shift
         for l in range(L):
             ll = layer_log[l]
@@ -243,7 +263,12 @@ def parse_and_verify(proof_bytes, oracle):
             ev = eadd(escale(ev, xf), cf)
         if ev != cur:
             raise VerifyError(f"query {q}: final polynomial mismatch")
-    if pos != len(words):
+    if pos != len(words) and not allow_trailing:
         raise VerifyError("trailing data in proof")
+    by_point = {}
+    k = 0
+    for p, b in order:
+        by_point[(p, b)] = openings[k:k + n_polys[b]]
+        k += n_polys[b]
     return {"log_n": log_n, "rate_bits": rb, "layers": L, "final_bits": final_bits, "zeta": zeta, "openings": openings,
-            "n_polys": n_polys, "queries": idxs}
+            "n_polys": n_polys, "queries": idxs, "points": zs_pt, "openings_at": by_point, "caps": caps, "end": pos}

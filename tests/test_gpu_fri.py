@@ -99,6 +99,29 @@ def test_prove_then_verify(setup, pkg, oracle, log_n, polys, rb, cap_h, a, fb, n
         b.free()
 
 
+def test_two_opening_points(setup, pkg, oracle):
+    """zeta and w_n*zeta (the "next row" point), second point only for the second batch"""
+    prover, _ = setup
+    rng = np.random.default_rng(21)
+    log_n, rb, cap_h = 11, 3, 4
+    b0, v0 = commit(pkg, prover, rng, log_n, 6, rb, cap_h)
+    b1, v1 = commit(pkg, prover, rng, log_n, 3, rb, cap_h)
+    g = pow(7, (P - 1) >> log_n, P)
+    proof = prover.fri_prove([b0, b1], rb, cap_h, num_queries=10, pow_bits=6, point_mults=(1, g), open_masks=[1, 3])
+    info = fv.parse_and_verify(proof, oracle)
+    assert sorted(info["openings_at"].keys()) == [(0, 0), (0, 1), (1, 1)]
+    co = v1.copy()
+    oracle.orc_ntt(ptr(co), log_n, 3, 1)
+    z1 = info["points"][1]
+    assert z1 == fv.escale(info["zeta"], g)
+    acc = (0, 0)
+    for cf in reversed([int(v) for v in co[2]]):
+        acc = fv.eadd(fv.emul(acc, z1), (cf, 0))
+    assert info["openings_at"][(1, 1)][2] == acc
+    b0.free()
+    b1.free()
+
+
 def test_tampered_proofs_are_rejected(setup, pkg, oracle):
     prover, _ = setup
     rng = np.random.default_rng(77)

@@ -1,0 +1,80 @@
+"""Rows a6 / a7 and the prover driver on the GPU: permutation products and quotient inside a
+complete proof of the build-defined circuit, accepted by the independent verifier
+(tests/plonk_ref.py on top of tests/fri_verifier.py); invalid witnesses and tampered proofs
+are rejected."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fri_verifier as fv  # noqa: E402
+import plonk_ref as pref  # noqa: E402
+from conftest import P, poseidon_consts, ptr  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def setup(prover, oracle):
+    rc, circ, diag = poseidon_consts("small")
+    prover.set_poseidon_constants(rc, circ, diag)
+    oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
+    return prover, oracle
+
+
+@pytest.mark.parametrize("log_n,W,nq,pw", [(6, 8, 8, 4), (8, 16, 10, 6), (10, 32, 12, 8), (12, 80, 28, 12)])
+def test_prove_and_verify(setup, pkg, log_n, W, nq, pw):
+    prover, oracle = setup
+    rng = np.random.default_rng(log_n * 100 + W)
+    circ = pref.build_circuit(rng, log_n, W)
+    ck = pkg.PlonkCircuit(prover, circ["consts"], circ["sigmas"])
+    proof = ck.prove(circ["wires"], num_queries=nq, pow_bits=pw)
+    info = pref.verify_plonk(proof, oracle)
+    assert info["log_n"] == log_n and info["W"] == W
+    assert ck.prove(circ["wires"], num_queries=nq, pow_bits=pw) == proof      # deterministic
+    ck.free()
+
+
+def test_invalid_witness_cannot_be_proved(setup, pkg):
+    """a gate violation or a broken copy constraint makes the quotient a non-polynomial: the
+    prover refuses (degree check of the final FRI polynomial) or the verifier rejects"""
+    prover, oracle = setup
+    rng = np.random.default_rng(9)
+    circ = pref.build_circuit(rng, 8, 16, copy_prob=0.8)
+    ck = pkg.PlonkCircuit(prover, circ["consts"], circ["sigmas"])
+    pref.verify_plonk(ck.prove(circ["wires"], 8, 4), oracle)
+    for kind in ("gate", "copy"):
+        bad = circ["wires"].copy()
+        if kind == "gate":
+            rows = np.nonzero(circ["consts"][0])[0]
+            bad[3, rows[5]] = (int(bad[3, rows[5]]) + 1) % P          # output of an active gate
+        else:
+            bad[0, 200] = (int(bad[0, 200]) + 1) % P                  # an input cell (likely in a copy class)
+            q, c0, c1 = (int(circ["consts"][k, 200]) for k in range(3))
+            bad[3, 200] = (c0 * int(bad[0, 200]) * int(bad[1, 200]) + c1 * int(bad[2, 200])) % P if q else bad[3, 200]
+        try:
+            proof = ck.prove(bad, 8, 4)
+        except pkg.GlpError:
+            continue
+        with pytest.raises(fv.VerifyError):
+            pref.verify_plonk(proof, oracle)
+    ck.free()
+
+
+def test_tampered_plonk_proof_rejected(setup, pkg):
+    prover, oracle = setup
+    rng = np.random.default_rng(10)
+    circ = pref.build_circuit(rng, 7, 8)
+    ck = pkg.PlonkCircuit(prover, circ["consts"], circ["sigmas"])
+    proof = ck.prove(circ["wires"], 6, 4)
+    pref.verify_plonk(proof, oracle)
+    words = np.frombuffer(proof, dtype="<u8").copy()
+    n = len(words)
+    for t in sorted(set([1, 2, 4, 6, 70, 140, 200, 270, 300, 330, 400, n // 2, n - 3] + list(range(280, n, max(1, n // 40))))):
+        bad = words.copy()
+        bad[t] ^= np.uint64(1)
+        with pytest.raises(Exception):
+            pref.verify_plonk(bad.tobytes(), oracle)
+    ck.free()
