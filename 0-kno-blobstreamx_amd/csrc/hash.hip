@@ -65,9 +65,9 @@ extern "C" int glp_set_poseidon_constants(glp_ctx* c, const uint64_t* rc, size_t
         all[360 + i] = circ[i]; all[372 + i] = diag[i];
         sum += circ[i];
         if (diag[i] > maxdiag) maxdiag = diag[i];
-        if (circ[i] >> 32 || diag[i] >> 32) small = false;
+        if (circ[i] >> 24 || diag[i] >> 24) small = false;
     }
-    if (sum + maxdiag >= ((unsigned __int128)1 << 32)) small = false;
+    if (sum + maxdiag >= ((unsigned __int128)1 << 24)) small = false;   // bound the fast MDS path relies on (hash_kernels.cuh)
     glp_hash_state* h = hs(c);
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!h->d_consts) GLP_HIPCHK(c, hipMalloc((void**)&h->d_consts, 384 * 8));

@@ -10,10 +10,11 @@
 // real table is supplied.
 //
 // One permutation per work-item, the 12-word state in 24 VGPRs; constants are read with
-// wave-uniform addresses (scalar loads).  When every MDS entry is < 2^32 and their sum is
-// < 2^32 (true for any small-integer MDS such as plonky2's), a row of the MDS layer is two
-// 64-bit accumulators of 32x32 products (lo halves and hi halves of the state) and ONE
-// 128-bit reduction, instead of twelve full field multiplications.
+// wave-uniform addresses (scalar loads).  When every MDS entry and their sum is < 2^24 (true
+// for any small-integer MDS such as plonky2's), a row of the MDS layer is two 64-bit
+// accumulators of 32x32 products (lo halves and hi halves of the state) and one cheap fix-up,
+// instead of twelve full field multiplications; the next round's constants ride along in
+// the accumulators.
 //
 // Plain HIP C++ without AMD builtins: tests/emu runs these bodies on the CPU.
 #pragma once
@@ -38,9 +39,16 @@ GL_HD u64 glp_sbox7(u64 x) {
     return gl_mul(x3, x4);
 }
 
-// s <- MDS * s  with  row r = sum_i s[(i + r) % 12] * circ[i] + s[r] * diag[r]
+// s <- MDS * s (+ rc_next)  with  row r = sum_i s[(i + r) % 12] * circ[i] + s[r] * diag[r].
+// rc_next (nullable) = the NEXT round's constants, folded into the accumulators so that the
+// constant layer costs no VALU work of its own.
+// SMALL (every entry and their sum < 2^24): a row is two 64-bit accumulators of 32x32 products,
+//   al = sum lo_i c_i + rc_lo,  ah = sum hi_i c_i + rc_hi   (both < 2^57),
+// and  al + ah*2^32 = al + (ah mod 2^32)*2^32 + (ah >> 32)*(2^32 - 1)  (mod p)  overflows 2^64 at
+// most once, so one fused carry/canonical fix-up finishes the row (9 VALU instead of a generic
+// 128-bit reduction).
 template <bool SMALL>
-GL_HD void glp_mds_layer(u64 (&s)[12], const u64* __restrict__ circ, const u64* __restrict__ diag) {
+GL_HD void glp_mds_layer(u64 (&s)[12], const u64* __restrict__ circ, const u64* __restrict__ diag, const u64* __restrict__ rc_next) {
     u64 out[12];
     if constexpr (SMALL) {
         u32 lo[12], hi[12], c[12], dg[12];
@@ -51,16 +59,19 @@ GL_HD void glp_mds_layer(u64 (&s)[12], const u64* __restrict__ circ, const u64* 
         });
         glp_hfor<0, 12>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
-            u64 al = (u64)lo[r] * dg[r], ah = (u64)hi[r] * dg[r];
+            const u64 k = rc_next ? rc_next[r] : 0ull;
+            u64 al = (u64)lo[r] * dg[r] + (u32)k, ah = (u64)hi[r] * dg[r] + (k >> 32);
             glp_hfor<0, 12>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
                 al += (u64)lo[(i + r) % 12] * c[i];
                 ah += (u64)hi[(i + r) % 12] * c[i];
             });
-            // value = al + ah * 2^32  (al, ah < 2^64)
-            u64 l = al + (ah << 32);
-            u64 h = (ah >> 32) + (l < al ? 1ull : 0ull);
-            out[r] = gl_reduce128(h, l);
+            const u64 l = al + (ah << 32);
+            const bool c1 = l < al;
+            const u64 t = (ah >> 32) * GL_EPS;
+            const u64 v = l + t;
+            const bool c2 = v < l;
+            out[r] = v + ((c1 | c2 | (v >= GL_P)) ? GL_EPS : 0ULL);
         });
     } else {
         glp_hfor<0, 12>([&](auto r_) {
@@ -70,27 +81,29 @@ GL_HD void glp_mds_layer(u64 (&s)[12], const u64* __restrict__ circ, const u64* 
                 constexpr int i = decltype(i_)::value;
                 acc = gl_add(acc, gl_mul(s[(i + r) % 12], circ[i]));
             });
-            out[r] = acc;
+            out[r] = rc_next ? gl_add(acc, rc_next[r]) : acc;
         });
     }
     glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = out[i]; });
 }
 
+// 4 full, 22 partial, 4 full rounds; round = add constants, x^7 (all lanes / lane 0), MDS.
+// Written as: constants of round 0, then per round {S-box, MDS + constants of the next round}.
 template <bool SMALL>
 GL_HD void glp_poseidon_permute(u64 (&s)[12], const GlpPoseidonConsts& k) {
+    glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = gl_add(s[i], k.rc[i]); });
     int rnd = 0;
     for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
-        glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = glp_sbox7(gl_add(s[i], k.rc[rnd * 12 + i])); });
-        glp_mds_layer<SMALL>(s, k.circ, k.diag);
+        glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = glp_sbox7(s[i]); });
+        glp_mds_layer<SMALL>(s, k.circ, k.diag, k.rc + (rnd + 1) * 12);
     }
     for (int r = 0; r < GLP_POS_PARTIAL; r++, rnd++) {
-        glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = gl_add(s[i], k.rc[rnd * 12 + i]); });
         s[0] = glp_sbox7(s[0]);
-        glp_mds_layer<SMALL>(s, k.circ, k.diag);
+        glp_mds_layer<SMALL>(s, k.circ, k.diag, k.rc + (rnd + 1) * 12);
     }
     for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
-        glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = glp_sbox7(gl_add(s[i], k.rc[rnd * 12 + i])); });
-        glp_mds_layer<SMALL>(s, k.circ, k.diag);
+        glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = glp_sbox7(s[i]); });
+        glp_mds_layer<SMALL>(s, k.circ, k.diag, rnd + 1 < GLP_POS_ROUNDS ? k.rc + (rnd + 1) * 12 : nullptr);
     }
 }
 

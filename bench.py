@@ -199,6 +199,77 @@ def hash_bench():
     pr.close()
 
 
+def synthetic_circuit(pr, log_n, W, seed=1):
+    """a satisfiable instance of the build-defined circuit generated with numpy +
+    the GPU's own field ops: random inputs, paired-up input cells as copy constraints (sigma swaps
+    each pair), gate outputs w = c0*x*y + c1*z.  Returns (consts[3][n], sigmas[W][n], wires[W][n])."""
+    n, G = 1 << log_n, W // 4
+    rng = np.random.default_rng(seed)
+    p = 2**64 - 2**32 + 1
+    consts = np.empty((3, n), dtype=np.uint64)
+    consts[0] = 1
+    consts[1] = splitmix_fill(n, 11)
+    consts[2] = splitmix_fill(n, 12)
+    wires = splitmix_fill(W * n, 13).reshape(W, n)
+    in_cols = np.array([4 * g + k for g in range(G) for k in range(3)], dtype=np.int64)
+    K = len(in_cols) * n
+    perm = rng.permutation(K).astype(np.int64)
+    a, b = perm[0:K - 1:2], perm[1:K:2]
+    col_of = lambda flat: in_cols[flat // n]
+    row_of = lambda flat: flat % n
+    wires[col_of(b), row_of(b)] = wires[col_of(a), row_of(a)]          # paired cells carry equal values
+    for g in range(G):                                                   # outputs on the GPU
+        x, y, z = wires[4 * g], wires[4 * g + 1], wires[4 * g + 2]
+        xy = pr.field_op("mul", x, y)
+        wires[4 * g + 3] = pr.field_op("add", pr.field_op("mul", consts[1], xy), pr.field_op("mul", consts[2], z))
+    delta = np.zeros(n, dtype=np.uint64)
+    delta[1] = 1
+    wpow = pr.fft(delta)                                                 # w_n^i
+    ks = np.array([pow(7, j, p) for j in range(W)], dtype=np.uint64)
+    tgt_col = np.tile(np.arange(W, dtype=np.int64)[:, None], (1, n))
+    tgt_row = np.tile(np.arange(n, dtype=np.int64)[None, :], (W, 1))
+    tgt_col[col_of(a), row_of(a)], tgt_row[col_of(a), row_of(a)] = col_of(b), row_of(b)
+    tgt_col[col_of(b), row_of(b)], tgt_row[col_of(b), row_of(b)] = col_of(a), row_of(a)
+    sigmas = pr.field_op("mul", ks[tgt_col], wpow[tgt_row])
+    return consts, sigmas, wires
+
+
+def prove_bench(sizes, quiet=False):
+    """end-to-end prove time of the BUILD'S OWN circuit (not the upstream CombinedStep circuit,
+    whose definition is not in the reference mount) sized like BASELINE configs[1]"""
+    import importlib
+    pkg = graft.load_package()
+    pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    pr = pkg.Prover(0)
+    rc, circ, diag = pc.default_constants()
+    pr.set_poseidon_constants(np.array(rc, dtype=np.uint64), np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64))
+    out = []
+    for log_n, W in sizes:
+        consts, sigmas, wires = synthetic_circuit(pr, log_n, W)
+        t0 = time.perf_counter()
+        ck = pkg.PlonkCircuit(pr, consts, sigmas)
+        pr.sync()
+        t1 = time.perf_counter()
+        dw = pr.to_device(wires)
+        times = []
+        proof = None
+        for _ in range(3):
+            pr.sync()
+            ta = time.perf_counter()
+            proof = ck.prove_(dw, 28, 16)
+            times.append(time.perf_counter() - ta)
+        res = {"stage": "plonk_prove", "circuit": "build-defined arithmetic+permutation circuit (DESIGN.md 3.6), NOT upstream's",
+               "log_n": log_n, "wires": W, "setup_s_incl_h2d": round(t1 - t0, 3), "prove_s": [round(t, 4) for t in times],
+               "prove_s_best": round(min(times), 4), "proof_bytes": len(proof), "queries": 28, "pow_bits": 16}
+        if not quiet:
+            print(json.dumps(res), flush=True)
+        out.append(res)
+        dw.free()
+        ck.free()
+    pr.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,14 +279,18 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-sizes", action="store_true", help="skip the 2^20/2^22/2^24 sweep")
+    ap.add_argument("--no-prove", action="store_true", help="skip the end-to-end prove leg")
     ap.add_argument("--sweep", action="store_true", help="tuning aid: time alternative pass plans and exit")
     ap.add_argument("--hash-bench", action="store_true", help="tuning aid: Poseidon / LDE / Merkle stage times and exit")
+    ap.add_argument("--prove-bench", action="store_true", help="end-to-end prove time of the build-defined circuit and exit")
     args = ap.parse_args()
 
     if args.sweep:
         return sweep()
     if args.hash_bench:
         return hash_bench()
+    if args.prove_bench:
+        return prove_bench([(14, 16), (16, 80), (20, 80)])
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -305,6 +380,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(log_n)
     pr.close()
+    if rank == 0 and world == 1 and not args.no_prove:
+        # first half of the BASELINE metric, as far as it can be honoured: end-to-end prove time of
+        # the build's own 2^20-row circuit (configs[1] size); the upstream circuits are not in the mount
+        r = prove_bench([(20, 80)], quiet=True)[0]
+        out["prove"] = {"seconds": r["prove_s_best"], "circuit": r["circuit"], "log_n": 20, "wires": 80, "proof_bytes": r["proof_bytes"],
+                        "queries": 28, "pow_bits": 16, "note": "commit wires, Z/partial products, quotient, FRI openings; inputs resident in HBM"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

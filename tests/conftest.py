@@ -67,6 +67,11 @@ def poseidon_consts(kind):
     if kind == "small":
         return rc, np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64)
     rng = np.random.default_rng(4242)
+    if kind == "medium":   # largest entries the fast MDS path admits: all < 2^24 and sum < 2^24
+        circ = rng.integers(1 << 19, (1 << 20) - 1, 12).astype(np.uint64)
+        diag = rng.integers(1 << 19, (1 << 20) - 1, 12).astype(np.uint64)
+        assert int(circ.sum()) + int(diag.max()) < (1 << 24)
+        return rc, circ, diag
     return rc, rand_field(rng, 12), rand_field(rng, 12)
 
 

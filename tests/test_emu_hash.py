@@ -19,7 +19,7 @@ def consts384(kind):
     return np.concatenate([rc, circ, diag]).astype(np.uint64), (rc, circ, diag)
 
 
-@pytest.mark.parametrize("kind", ["small", "big"])
+@pytest.mark.parametrize("kind", ["small", "medium", "big"])
 def test_emulated_poseidon_permutation(emu, oracle, kind):
     c384, (rc, circ, diag) = consts384(kind)
     oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
@@ -27,13 +27,15 @@ def test_emulated_poseidon_permutation(emu, oracle, kind):
     st = rand_field(rng, (70, 12))
     st[0, :] = 0
     st[1, :] = P - 1
+    st[2, :] = (1 << 32) - 1
+    st[3, :] = P - (1 << 32)
     ref = st.copy()
     for i in range(ref.shape[0]):
         row = ref[i].copy()
         oracle.orc_poseidon_permute(ptr(row))
         ref[i] = row
     got = st.copy()
-    assert emu.emu_poseidon_permute(ptr(got), got.shape[0], ptr(c384), 1 if kind == "small" else 0) == 0
+    assert emu.emu_poseidon_permute(ptr(got), got.shape[0], ptr(c384), 0 if kind == "big" else 1) == 0
     assert np.array_equal(got, ref)
 
 

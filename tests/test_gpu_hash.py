@@ -29,7 +29,7 @@ def test_hashing_needs_constants(pkg):
     pr.close()
 
 
-@pytest.mark.parametrize("kind", ["small", "big"])
+@pytest.mark.parametrize("kind", ["small", "medium", "big"])
 def test_poseidon_permutation(prover, oracle, kind):
     use_consts(prover, oracle, kind)
     rng = np.random.default_rng(31)
