@@ -99,6 +99,8 @@ def load_library():
         "glp_fri_fold2": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint64, _vp]),
         "glp_sha256_trace": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp]),
         "glp_sha512_trace": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp]),
+        "glp_ed25519_witness": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint64, _vp]),
+        "glp_tm_merkle_root": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_uint64, _vp]),
         "glp_challenger_new": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
         "glp_challenger_free": (None, [_vp]),
         "glp_challenger_observe": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
@@ -440,6 +442,38 @@ class Prover:
         data = ctypes.string_at(proof.value, ln.value)
         self.lib.glp_free_host(proof)
         return data
+
+    def ed25519_witness(self, pubs, sigs, msgs):
+        """pubs/sigs/msgs: lists of bytes.  Returns [n][37] u64 records (glprover.h)."""
+        n = len(pubs)
+        stride = max(1, max((len(m) for m in msgs), default=1))
+        P = np.zeros((n, 32), dtype=np.uint8)
+        S = np.zeros((n, 64), dtype=np.uint8)
+        M = np.zeros((n, stride), dtype=np.uint8)
+        Ln = np.zeros(n, dtype=np.uint32)
+        for i in range(n):
+            P[i] = np.frombuffer(pubs[i], dtype=np.uint8)
+            S[i] = np.frombuffer(sigs[i], dtype=np.uint8)
+            M[i, :len(msgs[i])] = np.frombuffer(msgs[i], dtype=np.uint8)
+            Ln[i] = len(msgs[i])
+        dp, ds, dm, dl = (self.to_device(a) for a in (P, S, M, Ln))
+        do = self.alloc(max(8, n * 37 * 8))
+        self._chk(self.lib.glp_ed25519_witness(self.ctx, dp.ptr, ds.ptr, dm.ptr, stride, dl.ptr, n, do.ptr), "glp_ed25519_witness")
+        out = do.download((n, 37))
+        for b in (dp, ds, dm, dl, do):
+            b.free()
+        return out
+
+    def tm_merkle_root(self, leaves: bytes, leaf_len: int) -> bytes:
+        """Tendermint simple Merkle root of fixed-size leaves (validator set / header fields)"""
+        n = len(leaves) // leaf_len if leaf_len else 0
+        assert n * leaf_len == len(leaves)
+        d = self.to_device(np.frombuffer(leaves, dtype=np.uint8)) if n else None
+        out = ctypes.create_string_buffer(32)
+        self._chk(self.lib.glp_tm_merkle_root(self.ctx, d.ptr if d else None, leaf_len, n, out), "glp_tm_merkle_root")
+        if d:
+            d.free()
+        return out.raw
 
     def transpose(self, mat):
         m = np.ascontiguousarray(mat, dtype=np.uint64)

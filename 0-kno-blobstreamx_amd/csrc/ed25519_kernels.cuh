@@ -1,0 +1,333 @@
+// ed25519_kernels.cuh — Ed25519 signature verification witness (upstream
+// name recalled, unverified: curta's Ed25519 gadget / tendermintx validator signature check —
+// reference file:line NONE, the mount is empty).  Follows RFC 8032 §5.1.3 (point decoding),
+// §5.1.7 (verification, cofactorless [S]B = R + [k]A) and FIPS 180-4 SHA-512.
+//
+// One signature per work-item (the batch is one validator set: O(100) signatures, tiny volume;
+// the SHA-512 of R || A || M, the reduction mod L and both scalar multiplications run in the
+// kernel, the host only marshals bytes).  Field elements mod 2^255 - 19 are ten unsigned limbs
+// of alternating 26/25 bits; products are 32x32 -> 64 multiply-adds (v_mad_u64_u32).
+// Output record per signature (GLP_ED_REC u64 words, little-endian 4-limb integers):
+//   [0] valid  [1..4] k = SHA512(R||A||M) mod L  [5..8] Ax [9..12] Ay [13..16] Rx [17..20] Ry
+//   [21..24] P1x [25..28] P1y (P1 = [S]B)  [29..32] P2x [33..36] P2y (P2 = [k]A)   — all affine.
+// Plain HIP C++ without AMD builtins (tests/emu runs these bodies on the CPU).
+#pragma once
+#include "gl_field.cuh"
+
+#define GLP_ED_REC 37
+
+struct glp_fe { u32 v[10]; };
+
+GL_HD int glp_fe_bits(int i) { return (i & 1) ? 25 : 26; }
+
+// weak reduction: limbs back under 2^26 / 2^25 (+ a small excess in limb 0)
+GL_HD void glp_fe_carry(u64 (&t)[10], glp_fe& o) {
+    u64 c = 0;
+    for (int r = 0; r < 2; r++) {
+        for (int i = 0; i < 10; i++) {
+            t[i] += c;
+            const int b = glp_fe_bits(i);
+            c = t[i] >> b;
+            t[i] &= (1ull << b) - 1;
+        }
+        c *= 19;                   // 2^255 = 19
+    }
+    t[0] += c;
+    for (int i = 0; i < 10; i++) o.v[i] = (u32)t[i];
+}
+GL_HD glp_fe glp_fe_add(const glp_fe& a, const glp_fe& b) {
+    u64 t[10];
+    for (int i = 0; i < 10; i++) t[i] = (u64)a.v[i] + b.v[i];
+    glp_fe o; glp_fe_carry(t, o); return o;
+}
+GL_HD glp_fe glp_fe_sub(const glp_fe& a, const glp_fe& b) {
+    // a + 4p - b, limb-wise (4p so that every limb stays non-negative for weakly reduced inputs)
+    u64 t[10];
+    for (int i = 0; i < 10; i++) {
+        const u64 fourp = (i == 0) ? 4ull * ((1ull << 26) - 19) : 4ull * ((1ull << glp_fe_bits(i)) - 1);
+        t[i] = (u64)a.v[i] + fourp - b.v[i];
+    }
+    glp_fe o; glp_fe_carry(t, o); return o;
+}
+GL_HD glp_fe glp_fe_mul(const glp_fe& a, const glp_fe& b) {
+    u64 t[19];
+    for (int i = 0; i < 19; i++) t[i] = 0;
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 10; j++) {
+            u64 pr = (u64)a.v[i] * b.v[j];
+            if ((i & 1) && (j & 1)) pr <<= 1;     // both odd limbs: exponent rounds up twice
+            t[i + j] += pr;
+        }
+    u64 r[10];
+    for (int i = 0; i < 9; i++) r[i] = t[i] + 19 * t[i + 10];
+    r[9] = t[9];
+    glp_fe o; glp_fe_carry(r, o); return o;
+}
+GL_HD glp_fe glp_fe_sq(const glp_fe& a) { return glp_fe_mul(a, a); }
+GL_HD glp_fe glp_fe_small(u32 x) { glp_fe o; for (int i = 0; i < 10; i++) o.v[i] = 0; o.v[0] = x; return o; }
+
+// a^(2^n)
+GL_HD glp_fe glp_fe_sqn(glp_fe a, int n) { for (int i = 0; i < n; i++) a = glp_fe_sq(a); return a; }
+// a^(2^252 - 3)  (the exponent (p-5)/8 used for square roots) and, from it, a^(p-2)
+GL_HD glp_fe glp_fe_pow2523(const glp_fe& z) {
+    glp_fe z2 = glp_fe_sq(z);                         // 2
+    glp_fe z9 = glp_fe_mul(glp_fe_sqn(z2, 2), z);     // 9
+    glp_fe z11 = glp_fe_mul(z9, z2);                  // 11
+    glp_fe z_5_0 = glp_fe_mul(glp_fe_sq(z11), z9);    // 2^5 - 1
+    glp_fe z_10_0 = glp_fe_mul(glp_fe_sqn(z_5_0, 5), z_5_0);
+    glp_fe z_20_0 = glp_fe_mul(glp_fe_sqn(z_10_0, 10), z_10_0);
+    glp_fe z_40_0 = glp_fe_mul(glp_fe_sqn(z_20_0, 20), z_20_0);
+    glp_fe z_50_0 = glp_fe_mul(glp_fe_sqn(z_40_0, 10), z_10_0);
+    glp_fe z_100_0 = glp_fe_mul(glp_fe_sqn(z_50_0, 50), z_50_0);
+    glp_fe z_200_0 = glp_fe_mul(glp_fe_sqn(z_100_0, 100), z_100_0);
+    glp_fe z_250_0 = glp_fe_mul(glp_fe_sqn(z_200_0, 50), z_50_0);   // 2^250 - 1
+    return glp_fe_mul(glp_fe_sqn(z_250_0, 2), z);                   // 2^252 - 3
+}
+GL_HD glp_fe glp_fe_inv(const glp_fe& z) {
+    // z^(p-2) = z^(2^255 - 21) = (z^(2^252-3))^8 * z^3
+    glp_fe t = glp_fe_sqn(glp_fe_pow2523(z), 3);
+    return glp_fe_mul(t, glp_fe_mul(glp_fe_sq(z), z));
+}
+
+// canonical little-endian 4 x u64
+GL_HD void glp_fe_pack(const glp_fe& a, u64 (&out)[4]) {
+    u64 t[10];
+    for (int i = 0; i < 10; i++) t[i] = a.v[i];
+    glp_fe w; glp_fe_carry(t, w);
+    for (int i = 0; i < 10; i++) t[i] = w.v[i];
+    glp_fe_carry(t, w);                         // now limb 0 < 2^26 + tiny, value < 2p
+    // subtract p if >= p, twice to be safe: compute w + 19 and see whether it overflows 2^255
+    for (int r = 0; r < 2; r++) {
+        u64 c = 19;
+        u32 q[10];
+        for (int i = 0; i < 10; i++) {
+            const u64 s = (u64)w.v[i] + c;
+            const int b = glp_fe_bits(i);
+            q[i] = (u32)(s & ((1ull << b) - 1));
+            c = s >> b;
+        }
+        if (c) for (int i = 0; i < 10; i++) w.v[i] = q[i];      // w >= p: w - p = w + 19 - 2^255
+    }
+    // 255 bits -> 4 words
+    unsigned __int128 acc = 0;
+    int accb = 0, oi = 0;
+    for (int k = 0; k < 4; k++) out[k] = 0;
+    for (int i = 0; i < 10; i++) {
+        acc |= (unsigned __int128)w.v[i] << accb;
+        accb += glp_fe_bits(i);
+        while (accb >= 64 && oi < 4) { out[oi++] = (u64)acc; acc >>= 64; accb -= 64; }
+    }
+    if (oi < 4) out[oi] = (u64)acc;
+}
+GL_HD glp_fe glp_fe_unpack(const u64 (&in)[4]) {   // low 255 bits
+    glp_fe o;
+    int bitpos = 0;
+    for (int i = 0; i < 10; i++) {
+        const int b = glp_fe_bits(i);
+        const int w = bitpos >> 6, sh = bitpos & 63;
+        u64 v = in[w] >> sh;
+        if (sh + b > 64 && w + 1 < 4) v |= in[w + 1] << (64 - sh);
+        o.v[i] = (u32)(v & ((1ull << b) - 1));
+        bitpos += b;
+    }
+    return o;
+}
+GL_HD bool glp_fe_eq(const glp_fe& a, const glp_fe& b) {
+    u64 x[4], y[4];
+    glp_fe_pack(a, x); glp_fe_pack(b, y);
+    return x[0] == y[0] && x[1] == y[1] && x[2] == y[2] && x[3] == y[3];
+}
+GL_HD bool glp_fe_is_zero(const glp_fe& a) { u64 x[4]; glp_fe_pack(a, x); return (x[0] | x[1] | x[2] | x[3]) == 0; }
+GL_HD u32 glp_fe_parity(const glp_fe& a) { u64 x[4]; glp_fe_pack(a, x); return (u32)(x[0] & 1); }
+
+// constants: d = -121665/121666, sqrt(-1), base point
+GL_HD glp_fe glp_fe_const(u64 w0, u64 w1, u64 w2, u64 w3) { const u64 in[4] = {w0, w1, w2, w3}; return glp_fe_unpack(in); }
+GL_HD glp_fe glp_ed_d() { return glp_fe_const(0x75eb4dca135978a3ull, 0x00700a4d4141d8abull, 0x8cc740797779e898ull, 0x52036cee2b6ffe73ull); }
+GL_HD glp_fe glp_ed_sqrtm1() { return glp_fe_const(0xc4ee1b274a0ea0b0ull, 0x2f431806ad2fe478ull, 0x2b4d00993dfbd7a7ull, 0x2b8324804fc1df0bull); }
+GL_HD glp_fe glp_ed_bx() { return glp_fe_const(0xc9562d608f25d51aull, 0x692cc7609525a7b2ull, 0xc0a4e231fdd6dc5cull, 0x216936d3cd6e53feull); }
+GL_HD glp_fe glp_ed_by() { return glp_fe_const(0x6666666666666658ull, 0x6666666666666666ull, 0x6666666666666666ull, 0x6666666666666666ull); }
+
+struct glp_pt { glp_fe X, Y, Z, T; };   // extended twisted Edwards coordinates
+
+GL_HD glp_pt glp_pt_add(const glp_pt& P, const glp_pt& Q) {
+    const glp_fe A = glp_fe_mul(glp_fe_sub(P.Y, P.X), glp_fe_sub(Q.Y, Q.X));
+    const glp_fe B = glp_fe_mul(glp_fe_add(P.Y, P.X), glp_fe_add(Q.Y, Q.X));
+    const glp_fe TT = glp_fe_mul(P.T, Q.T);
+    const glp_fe C = glp_fe_mul(glp_fe_add(TT, TT), glp_ed_d());
+    const glp_fe ZZ = glp_fe_mul(P.Z, Q.Z);
+    const glp_fe D = glp_fe_add(ZZ, ZZ);
+    const glp_fe E = glp_fe_sub(B, A), F = glp_fe_sub(D, C), G = glp_fe_add(D, C), H = glp_fe_add(B, A);
+    return {glp_fe_mul(E, F), glp_fe_mul(G, H), glp_fe_mul(F, G), glp_fe_mul(E, H)};
+}
+GL_HD glp_pt glp_pt_identity() { return {glp_fe_small(0), glp_fe_small(1), glp_fe_small(1), glp_fe_small(0)}; }
+GL_HD glp_pt glp_pt_from_affine(const glp_fe& x, const glp_fe& y) { return {x, y, glp_fe_small(1), glp_fe_mul(x, y)}; }
+
+// [s]P, s = 4 little-endian words (< 2^253), plain double-and-add from the top bit
+GL_HD glp_pt glp_pt_scalarmult(const u64 (&s)[4], const glp_pt& P) {
+    glp_pt Q = glp_pt_identity();
+    for (int bit = 255; bit >= 0; bit--) {
+        Q = glp_pt_add(Q, Q);
+        if ((s[bit >> 6] >> (bit & 63)) & 1) Q = glp_pt_add(Q, P);
+    }
+    return Q;
+}
+GL_HD void glp_pt_affine(const glp_pt& P, u64 (&x)[4], u64 (&y)[4]) {
+    const glp_fe zi = glp_fe_inv(P.Z);
+    glp_fe_pack(glp_fe_mul(P.X, zi), x);
+    glp_fe_pack(glp_fe_mul(P.Y, zi), y);
+}
+
+// RFC 8032 §5.1.3: decode 32 bytes (as 4 LE words) to an affine point; false when invalid
+GL_HD bool glp_ed_decode(const u64 (&enc)[4], glp_fe& x, glp_fe& y) {
+    const u32 sign = (u32)(enc[3] >> 63);
+    u64 yw[4] = {enc[0], enc[1], enc[2], enc[3] & 0x7fffffffffffffffull};
+    // y must be canonical (< p): p = 2^255 - 19
+    if (yw[3] == 0x7fffffffffffffffull && yw[2] == ~0ull && yw[1] == ~0ull && yw[0] >= 0xffffffffffffffedull) return false;
+    y = glp_fe_unpack(yw);
+    const glp_fe y2 = glp_fe_sq(y);
+    const glp_fe u = glp_fe_sub(y2, glp_fe_small(1));                       // y^2 - 1
+    const glp_fe v = glp_fe_add(glp_fe_mul(glp_ed_d(), y2), glp_fe_small(1)); // d y^2 + 1
+    // x = u v^3 (u v^7)^((p-5)/8)
+    const glp_fe v3 = glp_fe_mul(glp_fe_sq(v), v);
+    const glp_fe v7 = glp_fe_mul(glp_fe_sq(v3), v);
+    x = glp_fe_mul(glp_fe_mul(u, v3), glp_fe_pow2523(glp_fe_mul(u, v7)));
+    const glp_fe vx2 = glp_fe_mul(v, glp_fe_sq(x));
+    if (!glp_fe_eq(vx2, u)) {
+        if (glp_fe_eq(vx2, glp_fe_sub(glp_fe_small(0), u))) x = glp_fe_mul(x, glp_ed_sqrtm1());
+        else return false;
+    }
+    if (glp_fe_is_zero(x) && sign) return false;
+    if (glp_fe_parity(x) != sign) x = glp_fe_sub(glp_fe_small(0), x);
+    return true;
+}
+
+// ---- SHA-512 of R || A || M and reduction mod L -----------------------------------------------
+GL_HD u64 glp_ror64b(u64 x, int r) { return (x >> r) | (x << (64 - r)); }
+// k512: round constants.  byte(pos) supplies message bytes; total = message length in bytes.
+template <class ByteFn>
+GL_HD void glp_sha512_stream(ByteFn byte, u64 total, const u64* __restrict__ k512, u64 (&h)[8]) {
+    h[0] = 0x6a09e667f3bcc908ull; h[1] = 0xbb67ae8584caa73bull; h[2] = 0x3c6ef372fe94f82bull; h[3] = 0xa54ff53a5f1d36f1ull;
+    h[4] = 0x510e527fade682d1ull; h[5] = 0x9b05688c2b3e6c1full; h[6] = 0x1f83d9abfb41bd6bull; h[7] = 0x5be0cd19137e2179ull;
+    const u64 nblk = (total + 17 + 127) / 128;
+    for (u64 b = 0; b < nblk; b++) {
+        u64 w[16];
+        for (int i = 0; i < 16; i++) {
+            u64 v = 0;
+            for (int j = 0; j < 8; j++) {
+                const u64 pos = b * 128 + i * 8 + j;
+                u64 by = 0;
+                if (pos < total) by = byte(pos);
+                else if (pos == total) by = 0x80;
+                else if (pos >= nblk * 128 - 8) by = ((total * 8) >> (8 * (nblk * 128 - 1 - pos))) & 0xff;
+                v = (v << 8) | by;
+            }
+            w[i] = v;
+        }
+        u64 s0 = h[0], s1 = h[1], s2 = h[2], s3 = h[3], s4 = h[4], s5 = h[5], s6 = h[6], s7 = h[7];
+        for (int i = 0; i < 80; i++) {
+            u64 wi;
+            if (i < 16) wi = w[i];
+            else {
+                const u64 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+                const u64 g0 = glp_ror64b(w15, 1) ^ glp_ror64b(w15, 8) ^ (w15 >> 7);
+                const u64 g1 = glp_ror64b(w2, 19) ^ glp_ror64b(w2, 61) ^ (w2 >> 6);
+                wi = w[i & 15] + g0 + w[(i - 7) & 15] + g1;
+                w[i & 15] = wi;
+            }
+            const u64 S1 = glp_ror64b(s4, 14) ^ glp_ror64b(s4, 18) ^ glp_ror64b(s4, 41);
+            const u64 ch = (s4 & s5) ^ (~s4 & s6);
+            const u64 t1 = s7 + S1 + ch + k512[i] + wi;
+            const u64 S0 = glp_ror64b(s0, 28) ^ glp_ror64b(s0, 34) ^ glp_ror64b(s0, 39);
+            const u64 mj = (s0 & s1) ^ (s0 & s2) ^ (s1 & s2);
+            const u64 t2 = S0 + mj;
+            s7 = s6; s6 = s5; s5 = s4; s4 = s3 + t1; s3 = s2; s2 = s1; s1 = s0; s0 = t1 + t2;
+        }
+        h[0] += s0; h[1] += s1; h[2] += s2; h[3] += s3; h[4] += s4; h[5] += s5; h[6] += s6; h[7] += s7;
+    }
+}
+
+// x (8 LE words, 512 bits) mod L, L = 2^252 + 27742317777372353535851937790883648493; schoolbook
+// shift-and-subtract (260 steps of an 8-word compare/subtract: the volume is one hash per signature)
+GL_HD void glp_mod_l(const u64 (&x)[8], u64 (&r)[4]) {
+    const u64 Lw[4] = {0x5812631a5cf5d3edull, 0x14def9dea2f79cd6ull, 0x0000000000000000ull, 0x1000000000000000ull};
+    u64 a[9];
+    for (int i = 0; i < 8; i++) a[i] = x[i];
+    a[8] = 0;
+    for (int sh = 259; sh >= 0; sh--) {
+        // t = L << sh  (9 words)
+        u64 t[9];
+        const int ws = sh >> 6, bs = sh & 63;
+        for (int i = 0; i < 9; i++) {
+            u64 v = 0;
+            const int k = i - ws;
+            if (k >= 0 && k < 4) v = Lw[k] << bs;
+            if (bs && k - 1 >= 0 && k - 1 < 4) v |= Lw[k - 1] >> (64 - bs);
+            t[i] = v;
+        }
+        bool ge = true;
+        for (int i = 8; i >= 0; i--) { if (a[i] != t[i]) { ge = a[i] > t[i]; break; } }
+        if (ge) {
+            u64 br = 0;
+            for (int i = 0; i < 9; i++) {
+                const u64 d1 = a[i] - t[i];
+                const u64 b1 = a[i] < t[i];
+                const u64 d2 = d1 - br;
+                const u64 b2 = d1 < br;
+                a[i] = d2; br = b1 | b2;
+            }
+        }
+    }
+    for (int i = 0; i < 4; i++) r[i] = a[i];
+}
+GL_HD bool glp_scalar_lt_l(const u64 (&s)[4]) {
+    const u64 Lw[4] = {0x5812631a5cf5d3edull, 0x14def9dea2f79cd6ull, 0x0000000000000000ull, 0x1000000000000000ull};
+    for (int i = 3; i >= 0; i--) { if (s[i] != Lw[i]) return s[i] < Lw[i]; }
+    return false;
+}
+
+GL_HD u64 glp_load_le64(const uint8_t* p) { u64 v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | p[i]; return v; }
+
+// pubs [n][32], sigs [n][64], msgs [n][msg_stride] with lens[n]; out [n][GLP_ED_REC]
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(64) glp_ed25519_witness_kernel(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs,
+                                                                 const uint8_t* __restrict__ msgs, u32 msg_stride,
+                                                                 const u32* __restrict__ lens, u64 n, const u64* __restrict__ k512,
+                                                                 u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64* rec = out + i * GLP_ED_REC;
+    for (int k = 0; k < GLP_ED_REC; k++) rec[k] = 0;
+    const uint8_t* pub = pubs + i * 32;
+    const uint8_t* sig = sigs + i * 64;
+    const uint8_t* msg = msgs + i * (u64)msg_stride;
+    const u64 mlen = lens[i];
+    u64 Aenc[4], Renc[4], S[4];
+    for (int k = 0; k < 4; k++) { Aenc[k] = glp_load_le64(pub + 8 * k); Renc[k] = glp_load_le64(sig + 8 * k); S[k] = glp_load_le64(sig + 32 + 8 * k); }
+    glp_fe Ax, Ay, Rx, Ry;
+    const bool okA = glp_ed_decode(Aenc, Ax, Ay), okR = glp_ed_decode(Renc, Rx, Ry);
+    u64 w[4];
+    if (okA) { glp_fe_pack(Ax, w); for (int k = 0; k < 4; k++) rec[5 + k] = w[k]; glp_fe_pack(Ay, w); for (int k = 0; k < 4; k++) rec[9 + k] = w[k]; }
+    if (okR) { glp_fe_pack(Rx, w); for (int k = 0; k < 4; k++) rec[13 + k] = w[k]; glp_fe_pack(Ry, w); for (int k = 0; k < 4; k++) rec[17 + k] = w[k]; }
+    if (!okA || !okR || !glp_scalar_lt_l(S)) return;
+    u64 hh[8];
+    glp_sha512_stream([&](u64 pos) -> u64 { return pos < 32 ? sig[pos] : (pos < 64 ? pub[pos - 32] : msg[pos - 64]); }, 64 + mlen, k512, hh);
+    u64 hle[8];                                    // digest bytes as a little-endian integer
+    for (int k = 0; k < 8; k++) {
+        u64 v = hh[k], r = 0;
+        for (int b = 0; b < 8; b++) { r = (r << 8) | (v & 0xff); v >>= 8; }
+        hle[k] = r;
+    }
+    u64 kk[4];
+    glp_mod_l(hle, kk);
+    for (int k = 0; k < 4; k++) rec[1 + k] = kk[k];
+    const glp_pt P1 = glp_pt_scalarmult(S, glp_pt_from_affine(glp_ed_bx(), glp_ed_by()));
+    const glp_pt P2 = glp_pt_scalarmult(kk, glp_pt_from_affine(Ax, Ay));
+    u64 x1[4], y1[4], x2[4], y2[4], xr[4], yr[4];
+    glp_pt_affine(P1, x1, y1);
+    glp_pt_affine(P2, x2, y2);
+    for (int k = 0; k < 4; k++) { rec[21 + k] = x1[k]; rec[25 + k] = y1[k]; rec[29 + k] = x2[k]; rec[33 + k] = y2[k]; }
+    glp_pt_affine(glp_pt_add(glp_pt_from_affine(Rx, Ry), P2), xr, yr);
+    bool eq = true;
+    for (int k = 0; k < 4; k++) eq = eq && (x1[k] == xr[k]) && (y1[k] == yr[k]);
+    rec[0] = eq ? 1 : 0;
+}

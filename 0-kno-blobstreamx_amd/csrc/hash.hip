@@ -1,11 +1,13 @@
 // hash.hip — C-ABI entry points for Poseidon / Merkle / FRI fold / SHA-2 witness traces
 // (include/glprover.h).  Kernels: hash_kernels.cuh.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <vector>
 #include "glp_ctx.h"
 #include "hash_kernels.cuh"
 
 #include "hash_state.h"
+#include "ed25519_kernels.cuh"
 
 int glp_ntt_table(glp_ctx* c, int log_N, int inv, const u64** lo, const u64** hi);   // glprover.hip
 
@@ -198,6 +200,57 @@ extern "C" int glp_sha512_trace(glp_ctx* c, const uint8_t* d_blocks, uint64_t n_
     if (rc) return rc;
     hipLaunchKernelGGL(glp_sha512_trace_kernel<0>, dim3((unsigned)((n_msgs + 63) / 64)), dim3(64), 0, c->stream, d_blocks, n_msgs, bpm,
                        d_digests, d_trace, c->hash->d_k512);
+    GLP_HIPCHK(c, hipGetLastError());
+    return GLP_OK;
+}
+
+// Tendermint simple Merkle root of n fixed-size leaves (RFC 6962: 0x00/0x01 prefixes, split at the
+// largest power of two < n == pair adjacent nodes level by level, promoting an odd last node).
+extern "C" int glp_tm_merkle_root(glp_ctx* c, const uint8_t* d_leaves, uint32_t leaf_len, uint64_t n, uint8_t* h_root32) {
+    if (!c) return GLP_E_INVALID;
+    if (!h_root32 || (!d_leaves && n) || leaf_len == 0 || leaf_len > 118 || n > (1ull << 31)) { glp_set_err(c, "glp_tm_merkle_root: bad argument"); return GLP_E_INVALID; }
+    if (n == 0) {   // SHA256("")
+        static const uint8_t e[32] = {0xe3,0xb0,0xc4,0x42,0x98,0xfc,0x1c,0x14,0x9a,0xfb,0xf4,0xc8,0x99,0x6f,0xb9,0x24,0x27,0xae,0x41,0xe4,0x64,0x9b,0x93,0x4c,0xa4,0x95,0x99,0x1b,0x78,0x52,0xb8,0x55};
+        memcpy(h_root32, e, 32);
+        return GLP_OK;
+    }
+    int rc = ensure_sha_tables(c);
+    if (rc) return rc;
+    u32 *a = nullptr, *b = nullptr;
+    GLP_HIPCHK(c, hipMalloc((void**)&a, n * 32));
+    hipError_t e2 = hipMalloc((void**)&b, ((n + 1) / 2) * 32);
+    if (e2 != hipSuccess) { hipFree(a); glp_set_err(c, "glp_tm_merkle_root: alloc"); return GLP_E_NOMEM; }
+    hipLaunchKernelGGL(glp_tm_leaf_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_leaves, leaf_len, n, a, c->hash->d_k256);
+    u64 cnt = n;
+    u32 *src = a, *dst = b;
+    while (cnt > 1) {
+        const u64 nout = (cnt + 1) / 2;
+        hipLaunchKernelGGL(glp_tm_inner_kernel<0>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, c->stream, src, cnt, dst, c->hash->d_k256);
+        cnt = nout;
+        u32* t = src; src = dst; dst = t;
+    }
+    u32 hw[8];
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(hw, src, 32, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(a); hipFree(b);
+    if (e != hipSuccess) { glp_set_err(c, "glp_tm_merkle_root: %s", hipGetErrorString(e)); return GLP_E_HIP; }
+    for (int k = 0; k < 8; k++) { h_root32[4*k] = hw[k] >> 24; h_root32[4*k+1] = hw[k] >> 16; h_root32[4*k+2] = hw[k] >> 8; h_root32[4*k+3] = hw[k]; }
+    return GLP_OK;
+}
+
+// Ed25519 verification witness for a batch of signatures (row a10): pubs [n][32], sigs [n][64],
+// msgs [n][msg_stride] with lens[n] (all device); out [n][GLP_ED25519_RECORD_WORDS] u64.
+extern "C" int glp_ed25519_witness(glp_ctx* c, const uint8_t* d_pubs, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_stride,
+                                   const uint32_t* d_lens, uint64_t n, uint64_t* d_out) {
+    if (!c) return GLP_E_INVALID;
+    if ((!d_pubs || !d_sigs || !d_msgs || !d_lens || !d_out) && n) { glp_set_err(c, "glp_ed25519_witness: null buffer"); return GLP_E_INVALID; }
+    if (n == 0) return GLP_OK;
+    if (msg_stride == 0 || n > (1ull << 30)) { glp_set_err(c, "glp_ed25519_witness: bad size"); return GLP_E_INVALID; }
+    int rc = ensure_sha_tables(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(glp_ed25519_witness_kernel<0>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_pubs, d_sigs, d_msgs, msg_stride,
+                       d_lens, n, c->hash->d_k512, d_out);
     GLP_HIPCHK(c, hipGetLastError());
     return GLP_OK;
 }

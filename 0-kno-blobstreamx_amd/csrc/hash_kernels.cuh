@@ -282,3 +282,92 @@ __global__ void __launch_bounds__(256) glp_sha512_trace_kernel(const uint8_t* __
     }
     for (int i = 0; i < 8; i++) digests[m * 8 + i] = h[i];
 }
+
+// ---- Tendermint "simple" Merkle tree over SHA-256 (RFC 6962 domain separation) ----------------
+// The header / validator-set hashing of the light-client circuits (BASELINE configs[0]).
+// One SHA-256 compression core shared by the two kernels below.
+GL_HD void glp_sha256_compress_words(u32 (&h)[8], const u32 (&m)[16], const u32* __restrict__ k256) {
+    u32 w[16];
+    #pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = m[i];
+    u32 s0 = h[0], s1 = h[1], s2 = h[2], s3 = h[3], s4 = h[4], s5 = h[5], s6 = h[6], s7 = h[7];
+    #pragma unroll
+    for (int i = 0; i < 64; i++) {
+        u32 wi;
+        if (i < 16) wi = w[i];
+        else {
+            const u32 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            const u32 g0 = glp_ror32(w15, 7) ^ glp_ror32(w15, 18) ^ (w15 >> 3);
+            const u32 g1 = glp_ror32(w2, 17) ^ glp_ror32(w2, 19) ^ (w2 >> 10);
+            wi = w[i & 15] + g0 + w[(i - 7) & 15] + g1;
+            w[i & 15] = wi;
+        }
+        const u32 S1 = glp_ror32(s4, 6) ^ glp_ror32(s4, 11) ^ glp_ror32(s4, 25);
+        const u32 ch = (s4 & s5) ^ (~s4 & s6);
+        const u32 t1 = s7 + S1 + ch + k256[i] + wi;
+        const u32 S0 = glp_ror32(s0, 2) ^ glp_ror32(s0, 13) ^ glp_ror32(s0, 22);
+        const u32 mj = (s0 & s1) ^ (s0 & s2) ^ (s1 & s2);
+        const u32 t2 = S0 + mj;
+        s7 = s6; s6 = s5; s5 = s4; s4 = s3 + t1; s3 = s2; s2 = s1; s1 = s0; s0 = t1 + t2;
+    }
+    h[0] += s0; h[1] += s1; h[2] += s2; h[3] += s3; h[4] += s4; h[5] += s5; h[6] += s6; h[7] += s7;
+}
+
+// leaf hashes: out[i] = SHA256(0x00 || leaf_i), leaves of fixed leaf_len <= 118 bytes (two blocks max).
+// digests are 8 big-endian words stored as u32.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_tm_leaf_kernel(const uint8_t* __restrict__ leaves, u32 leaf_len, u64 n, u32* __restrict__ out,
+                                                          const u32* __restrict__ k256) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = leaves + i * leaf_len;
+    const u32 total = leaf_len + 1;                       // with the 0x00 prefix
+    const u32 nblk = (total + 9 + 63) / 64;
+    u32 h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    for (u32 b = 0; b < nblk; b++) {
+        u32 m[16];
+        for (int wd = 0; wd < 16; wd++) {
+            u32 v = 0;
+            for (int k = 0; k < 4; k++) {
+                const u32 pos = b * 64 + wd * 4 + k;      // byte position in the padded message
+                u32 byte = 0;
+                if (pos == 0) byte = 0x00;
+                else if (pos < total) byte = p[pos - 1];
+                else if (pos == total) byte = 0x80;
+                else if (pos >= nblk * 64 - 8) { const u64 bits = (u64)total * 8; byte = (u32)(bits >> (8 * (nblk * 64 - 1 - pos))) & 0xff; }
+                v = (v << 8) | byte;
+            }
+            m[wd] = v;
+        }
+        glp_sha256_compress_words(h, m, k256);
+    }
+    for (int k = 0; k < 8; k++) out[i * 8 + k] = h[k];
+}
+
+// one level: out[i] = SHA256(0x01 || in[2i] || in[2i+1]) for i < n/2; an odd last node is promoted.
+// The 65-byte message is two blocks.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_tm_inner_kernel(const u32* __restrict__ in, u64 n, u32* __restrict__ out,
+                                                           const u32* __restrict__ k256) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 n_out = (n + 1) / 2;
+    if (i >= n_out) return;
+    if (2 * i + 1 >= n) {                                  // promoted
+        for (int k = 0; k < 8; k++) out[i * 8 + k] = in[2 * i * 8 + k];
+        return;
+    }
+    u32 d[16];
+    for (int k = 0; k < 16; k++) d[k] = in[2 * i * 8 + k];   // left || right, big-endian words
+    u32 h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    u32 m[16];
+    // block 0: 0x01 then the first 63 bytes of (left||right): every word is shifted by one byte
+    m[0] = (0x01u << 24) | (d[0] >> 8);
+    for (int k = 1; k < 16; k++) m[k] = (d[k - 1] << 24) | (d[k] >> 8);
+    glp_sha256_compress_words(h, m, k256);
+    // block 1: the last byte of right, 0x80, zeros, length = 65*8 = 520 bits
+    for (int k = 0; k < 16; k++) m[k] = 0;
+    m[0] = (d[15] << 24) | (0x80u << 16);
+    m[15] = 520;
+    glp_sha256_compress_words(h, m, k256);
+    for (int k = 0; k < 8; k++) out[i * 8 + k] = h[k];
+}

@@ -181,6 +181,19 @@ int glp_sha256_trace(glp_ctx* ctx, const uint8_t* d_blocks, uint64_t n_msgs, uin
 int glp_sha512_trace(glp_ctx* ctx, const uint8_t* d_blocks, uint64_t n_msgs, uint32_t blocks_per_msg,
                      uint64_t* d_digests, uint64_t* d_trace);
 
+/* Ed25519 verification witness (row a10; upstream name recalled: curta Ed25519 gadget), RFC 8032
+ * cofactorless check [S]B = R + [k]A.  Per signature GLP_ED25519_RECORD_WORDS u64:
+ * [0] valid, [1..4] k = SHA512(R||A||M) mod L, then affine Ax, Ay, Rx, Ry, P1x, P1y (= [S]B),
+ * P2x, P2y (= [k]A), each 4 little-endian words.  The message bytes of signature i are
+ * d_msgs[i*msg_stride .. + d_lens[i]).  Stream-ordered (glp_sync before reading d_out). */
+#define GLP_ED25519_RECORD_WORDS 37
+int glp_ed25519_witness(glp_ctx* ctx, const uint8_t* d_pubs, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_stride,
+                        const uint32_t* d_lens, uint64_t n, uint64_t* d_out);
+
+/* Tendermint "simple" Merkle root (RFC 6962 prefixes) of n leaves of leaf_len (<= 118) bytes each:
+ * the validator-set / header hashing of BASELINE configs[0].  Synchronous; h_root32 = 32 bytes. */
+int glp_tm_merkle_root(glp_ctx* ctx, const uint8_t* d_leaves, uint32_t leaf_len, uint64_t n, uint8_t* h_root32);
+
 /* Multi-GPU (row a11 / SURVEY §8e): leaf subproofs shard one per GPU; the all-gather of the
  * padded proof blobs is done by the host through torch.distributed (RCCL) — see bench.py /
  * INTEGRATION.md — so the C ABI has no communicator entry point. */

@@ -126,3 +126,35 @@ def test_emulated_sha2_traces(emu, oracle, pkg):
                 assert np.array_equal(tr[i], ref_tr)
             if block == 64:
                 assert hashlib.sha256(items[0][0]).hexdigest() == items[0][2]
+
+
+def test_emulated_tendermint_merkle_root(emu):
+    """validator-set style hashing (BASELINE configs[0]) vs the committed hashlib-generated vectors"""
+    k256, _ = k_tables()
+    with open(os.path.join(G, "tendermint_merkle.json")) as f:
+        t = json.load(f)
+    for c in t["cases"]:
+        if c["n"] == 0:
+            continue
+        leaves = bytes.fromhex(c["leaves"])
+        out = ctypes.create_string_buffer(32)
+        assert emu.emu_tm_merkle_root(leaves, t["leaf_len"], c["n"], k256.ctypes.data, out) == 0
+        assert out.raw.hex() == c["root"], c["n"]
+    # other leaf lengths, including the two-block boundary (55/56 bytes with the prefix)
+    import hashlib
+
+    def tm_root(items):
+        if len(items) == 1:
+            return hashlib.sha256(b"\x00" + items[0]).digest()
+        k = 1
+        while k * 2 < len(items):
+            k *= 2
+        return hashlib.sha256(b"\x01" + tm_root(items[:k]) + tm_root(items[k:])).digest()
+
+    rng = np.random.default_rng(3)
+    for leaf_len in (1, 32, 54, 55, 56, 63, 64, 118):
+        n = int(rng.integers(1, 20))
+        items = [rng.integers(0, 256, leaf_len, dtype=np.uint8).tobytes() for _ in range(n)]
+        out = ctypes.create_string_buffer(32)
+        assert emu.emu_tm_merkle_root(b"".join(items), leaf_len, n, k256.ctypes.data, out) == 0
+        assert out.raw == tm_root(items), (leaf_len, n)

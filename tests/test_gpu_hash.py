@@ -136,3 +136,12 @@ def test_sha256_many_messages_vs_hashlib(prover, pkg):
     dig, _ = prover.sha256_trace(padded, 1, want_trace=False)
     for i in (0, 1, 999, 1999):
         assert b"".join(int(v).to_bytes(4, "big") for v in dig[i]) == hashlib.sha256(msgs[i]).digest()
+
+
+def test_tendermint_merkle_root(prover):
+    """BASELINE configs[0] shape: validator-set hashing, 100 validators of 40-byte leaves, and the
+    other committed cases, vs hashlib-generated golden roots"""
+    with open(os.path.join(G, "tendermint_merkle.json")) as f:
+        t = json.load(f)
+    for c in t["cases"]:
+        assert prover.tm_merkle_root(bytes.fromhex(c["leaves"]), t["leaf_len"]).hex() == c["root"], c["n"]
