@@ -18,7 +18,7 @@ struct glp_challenger {
     std::vector<u64> consts;
     bool small_mds;
     void permute() {
-        GlpPoseidonConsts k{consts.data(), consts.data() + 360, consts.data() + 372};
+        GlpPoseidonConsts k{consts.data(), consts.data() + 360, consts.data() + 372, nullptr, nullptr};   // plain rounds on the host
         if (small_mds) glp_poseidon_permute<true>(state, k);
         else glp_poseidon_permute<false>(state, k);
     }

@@ -7,6 +7,7 @@
 #include "hash_kernels.cuh"
 
 #include "hash_state.h"
+#include "poseidon_precomp.h"
 #include "ed25519_kernels.cuh"
 
 int glp_ntt_table(glp_ctx* c, int log_N, int inv, const u64** lo, const u64** hi);   // glprover.hip
@@ -48,11 +49,13 @@ void glp_hash_destroy(glp_ctx* c) {
     if (c->hash->d_consts) hipFree(c->hash->d_consts);
     if (c->hash->d_k256) hipFree(c->hash->d_k256);
     if (c->hash->d_k512) hipFree(c->hash->d_k512);
+    if (c->hash->d_pg_coef) hipFree(c->hash->d_pg_coef);
+    if (c->hash->d_pg_cst) hipFree(c->hash->d_pg_cst);
     delete c->hash;
     c->hash = nullptr;
 }
 
-static GlpPoseidonConsts consts_of(glp_hash_state* h) { return GlpPoseidonConsts{h->d_consts, h->d_consts + 360, h->d_consts + 372}; }
+static GlpPoseidonConsts consts_of(glp_hash_state* h) { return glp_dev_consts(h); }
 
 extern "C" int glp_set_poseidon_constants(glp_ctx* c, const uint64_t* rc, size_t n_rc, const uint64_t* circ, const uint64_t* diag) {
     if (!c) return GLP_E_INVALID;
@@ -77,6 +80,18 @@ extern "C" int glp_set_poseidon_constants(glp_ctx* c, const uint64_t* rc, size_t
     h->h_consts = all;
     h->have_consts = true;
     h->small_mds = small;
+    // grouped partial rounds: only for small-integer MDS whose cubes stay small
+    if (h->d_pg_coef) { hipFree(h->d_pg_coef); h->d_pg_coef = nullptr; }
+    if (h->d_pg_cst) { hipFree(h->d_pg_cst); h->d_pg_cst = nullptr; }
+    h->h_pg_coef.clear(); h->h_pg_cst.clear();
+    if (small && glp_poseidon_group_tables(all.data(), h->h_pg_coef, h->h_pg_cst)) {
+        GLP_HIPCHK(c, hipMalloc((void**)&h->d_pg_coef, h->h_pg_coef.size() * 4));
+        GLP_HIPCHK(c, hipMalloc((void**)&h->d_pg_cst, h->h_pg_cst.size() * 8));
+        GLP_HIPCHK(c, hipMemcpy(h->d_pg_coef, h->h_pg_coef.data(), h->h_pg_coef.size() * 4, hipMemcpyHostToDevice));
+        GLP_HIPCHK(c, hipMemcpy(h->d_pg_cst, h->h_pg_cst.data(), h->h_pg_cst.size() * 8, hipMemcpyHostToDevice));
+    } else {
+        h->h_pg_coef.clear(); h->h_pg_cst.clear();
+    }
     return GLP_OK;
 }
 

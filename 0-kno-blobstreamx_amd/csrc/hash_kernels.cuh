@@ -30,7 +30,14 @@ struct GlpPoseidonConsts {
     const u64* rc;     // [30][12]
     const u64* circ;   // [12]
     const u64* diag;   // [12]
+    // grouped partial rounds (nullptr = plain): per group of 3 rounds GLP_PG_COEF u32 + GLP_PG_CST u64
+    const u32* pg_coef;
+    const u64* pg_cst;
 };
+#define GLP_PG_K 3                 // partial rounds per group
+#define GLP_PG_GROUPS 7            // 7 x 3 = 21 of the 22 partial rounds; the last one runs plain
+#define GLP_PG_COEF (12 + 13 + 12 * 14)
+#define GLP_PG_CST (1 + 1 + 12)
 
 #define glp_hfor glp_static_for
 
@@ -87,6 +94,50 @@ GL_HD void glp_mds_layer(u64 (&s)[12], const u64* __restrict__ circ, const u64* 
     glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = out[i]; });
 }
 
+// sum_i v_i * coef_i + cst (mod p) for small integer coefficients (each < 2^24, sum < 2^26): the
+// lo and hi 32-bit halves of the v_i accumulate separately in 64 bits (no carries inside the sum),
+// and one fused fix-up reduces  al + ah * 2^32  (see glp_mds_layer).
+template <int N>
+GL_HD u64 glp_dot_small(const u32 (&lo)[N], const u32 (&hi)[N], const u32* __restrict__ coef, u64 cst) {
+    u64 al = (u32)cst, ah = cst >> 32;
+    glp_hfor<0, N>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        al += (u64)lo[i] * coef[i];
+        ah += (u64)hi[i] * coef[i];
+    });
+    const u64 l = al + (ah << 32);
+    const bool c1 = l < al;
+    const u64 t = (ah >> 32) * GL_EPS;
+    const u64 v = l + t;
+    const bool c2 = v < l;
+    return v + ((c1 | c2 | (v >= GL_P)) ? GL_EPS : 0ULL);
+}
+
+// Three consecutive partial rounds at once.  Only lane 0 is non-linear, so the state before
+// round r0+j is an affine-linear function of (the 11 untouched lanes at r0, the S-box outputs
+// f_0..f_{j-1}): the host multiplies the small-integer MDS out ahead of time (entries of M^3
+// stay < 2^24) and the kernel evaluates two 12/13-term dot products for the next S-box inputs
+// and one 12 x 14 product for the state after the group: 193 multiply-adds and 14 fix-ups
+// instead of 432 and 36.  Identical results to three plain rounds (integer identities mod p).
+GL_HD void glp_partial_group(u64 (&s)[12], const u32* __restrict__ cf, const u64* __restrict__ cs) {
+    u32 lo[14], hi[14];                         // [0..10] = lanes 1..11 at r0, [11..13] = f_0..f_2
+    glp_hfor<0, 11>([&](auto i_) { constexpr int i = decltype(i_)::value; lo[i] = (u32)s[i + 1]; hi[i] = (u32)(s[i + 1] >> 32); });
+    const u64 f0 = glp_sbox7(s[0]);
+    lo[11] = (u32)f0; hi[11] = (u32)(f0 >> 32);
+    u32 l12[12], h12[12];
+    glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; l12[i] = lo[i]; h12[i] = hi[i]; });
+    const u64 f1 = glp_sbox7(glp_dot_small<12>(l12, h12, cf, cs[0]));
+    lo[12] = (u32)f1; hi[12] = (u32)(f1 >> 32);
+    u32 l13[13], h13[13];
+    glp_hfor<0, 13>([&](auto i_) { constexpr int i = decltype(i_)::value; l13[i] = lo[i]; h13[i] = hi[i]; });
+    const u64 f2 = glp_sbox7(glp_dot_small<13>(l13, h13, cf + 12, cs[1]));
+    lo[13] = (u32)f2; hi[13] = (u32)(f2 >> 32);
+    glp_hfor<0, 12>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        s[r] = glp_dot_small<14>(lo, hi, cf + 25 + 14 * r, cs[2 + r]);
+    });
+}
+
 // 4 full, 22 partial, 4 full rounds; round = add constants, x^7 (all lanes / lane 0), MDS.
 // Written as: constants of round 0, then per round {S-box, MDS + constants of the next round}.
 template <bool SMALL>
@@ -97,7 +148,14 @@ GL_HD void glp_poseidon_permute(u64 (&s)[12], const GlpPoseidonConsts& k) {
         glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = glp_sbox7(s[i]); });
         glp_mds_layer<SMALL>(s, k.circ, k.diag, k.rc + (rnd + 1) * 12);
     }
-    for (int r = 0; r < GLP_POS_PARTIAL; r++, rnd++) {
+    int r = 0;
+    if constexpr (SMALL) {
+        if (k.pg_coef) {
+            for (int g = 0; g < GLP_PG_GROUPS; g++, r += GLP_PG_K, rnd += GLP_PG_K)
+                glp_partial_group(s, k.pg_coef + g * GLP_PG_COEF, k.pg_cst + g * GLP_PG_CST);
+        }
+    }
+    for (; r < GLP_POS_PARTIAL; r++, rnd++) {
         s[0] = glp_sbox7(s[0]);
         glp_mds_layer<SMALL>(s, k.circ, k.diag, k.rc + (rnd + 1) * 12);
     }

@@ -105,6 +105,7 @@ def emu():
     lib.emu_gl_mul_pow2.restype = ctypes.c_uint64
     lib.emu_gl_mul_pow2.argtypes = [ctypes.c_uint64, ctypes.c_int]
     lib.emu_poseidon_permute.argtypes = [u64p, ctypes.c_uint64, u64p, ctypes.c_int]
+    lib.emu_poseidon_grouped_available.argtypes = [u64p]
     lib.emu_merkle.argtypes = [u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u64p, u64p,
                                ctypes.c_int]
     lib.emu_fri_fold2.argtypes = [u64p, u64p, ctypes.c_uint32, ctypes.c_uint64, u64p]

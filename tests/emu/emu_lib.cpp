@@ -96,9 +96,22 @@ extern "C" u64 emu_gl_mul_pow2(u64 x, int s) {
 
 // ---- hash kernels under emulation -------------------------------------------------------
 #include "../../0-kno-blobstreamx_amd/csrc/hash_kernels.cuh"
+#include "../../0-kno-blobstreamx_amd/csrc/poseidon_precomp.h"
 
+// small != 0: fast MDS path; small == 2: also the grouped partial rounds
+static GlpPoseidonConsts emu_consts(const u64* c384, int small, std::vector<u32>& cf, std::vector<u64>& cs) {
+    GlpPoseidonConsts k{c384, c384 + 360, c384 + 372, nullptr, nullptr};
+    if (small == 2 && glp_poseidon_group_tables(c384, cf, cs)) { k.pg_coef = cf.data(); k.pg_cst = cs.data(); }
+    return k;
+}
+
+extern "C" int emu_poseidon_grouped_available(const u64* consts384) {
+    std::vector<u32> cf; std::vector<u64> cs;
+    return glp_poseidon_group_tables(consts384, cf, cs) ? 1 : 0;
+}
 extern "C" int emu_poseidon_permute(u64* states, u64 n, const u64* consts384, int small) {
-    GlpPoseidonConsts k{consts384, consts384 + 360, consts384 + 372};
+    std::vector<u32> cf; std::vector<u64> cs;
+    GlpPoseidonConsts k = emu_consts(consts384, small, cf, cs);
     unsigned block = 64, grid = (unsigned)((n + block - 1) / block);
     if (small) glp_emu_launch(grid, block, 0, [&] { glp_poseidon_permute_kernel<true>(states, n, k); });
     else glp_emu_launch(grid, block, 0, [&] { glp_poseidon_permute_kernel<false>(states, n, k); });
@@ -107,7 +120,8 @@ extern "C" int emu_poseidon_permute(u64* states, u64 n, const u64* consts384, in
 
 extern "C" int emu_merkle(const u64* src, u64 stride, int poly_major, u32 leaf_len, u32 log_leaves, u32 cap_h, u64* digests,
                           const u64* consts384, int small) {
-    GlpPoseidonConsts k{consts384, consts384 + 360, consts384 + 372};
+    std::vector<u32> cf; std::vector<u64> cs;
+    GlpPoseidonConsts k = emu_consts(consts384, small, cf, cs);
     const u64 nl = 1ull << log_leaves;
     unsigned block = 64, grid = (unsigned)((nl + block - 1) / block);
     auto leaves = [&](auto sm_, auto pm_) {
@@ -204,7 +218,8 @@ extern "C" int emu_fri_combine(const u64* lde, u32 n_polys, u32 log_N, const u64
 }
 
 extern "C" int emu_pow(const u64* seed, u64 base, u64 count, u32 pow_bits, const u64* consts384, int small, unsigned long long* found) {
-    GlpPoseidonConsts k{consts384, consts384 + 360, consts384 + 372};
+    std::vector<u32> cf; std::vector<u64> cs;
+    GlpPoseidonConsts k = emu_consts(consts384, small, cf, cs);
     *found = ~0ull;
     if (small) glp_emu_launch((unsigned)((count + 63) / 64), 64, 0, [&] { glp_pow_kernel<true>(seed, base, count, pow_bits, found, k); });
     else glp_emu_launch((unsigned)((count + 63) / 64), 64, 0, [&] { glp_pow_kernel<false>(seed, base, count, pow_bits, found, k); });

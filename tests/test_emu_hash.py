@@ -37,6 +37,14 @@ def test_emulated_poseidon_permutation(emu, oracle, kind):
     got = st.copy()
     assert emu.emu_poseidon_permute(ptr(got), got.shape[0], ptr(c384), 0 if kind == "big" else 1) == 0
     assert np.array_equal(got, ref)
+    if kind == "small":
+        # grouped partial rounds (three rounds per dot-product group) give the same permutation
+        assert emu.emu_poseidon_grouped_available(ptr(c384)) == 1
+        got = st.copy()
+        assert emu.emu_poseidon_permute(ptr(got), got.shape[0], ptr(c384), 2) == 0
+        assert np.array_equal(got, ref)
+    if kind == "medium":
+        assert emu.emu_poseidon_grouped_available(ptr(c384)) == 0      # cubes of 2^20 entries are not small
 
 
 @pytest.mark.parametrize("kind,leaf_len,log_leaves,cap_h", [("small", 135, 7, 2), ("small", 3, 6, 0), ("small", 4, 5, 5),
@@ -55,7 +63,7 @@ def test_emulated_merkle(emu, oracle, kind, leaf_len, log_leaves, cap_h):
     # polynomial-major source gives the same tree
     polys = np.ascontiguousarray(leaves.T)
     dig2 = np.zeros_like(dig_ref)
-    assert emu.emu_merkle(ptr(polys), 1 << log_leaves, 1, leaf_len, log_leaves, cap_h, ptr(dig2), ptr(c384), small) == 0
+    assert emu.emu_merkle(ptr(polys), 1 << log_leaves, 1, leaf_len, log_leaves, cap_h, ptr(dig2), ptr(c384), 2 if small else 0) == 0
     assert np.array_equal(dig2, dig_ref)
 
 
