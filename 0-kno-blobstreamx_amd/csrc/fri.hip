@@ -145,7 +145,10 @@ extern "C" int glp_pow_grind(glp_ctx* c, const uint64_t* h_seed4, uint32_t pow_b
     GLP_HIPCHK(c, seed.alloc(32));
     GLP_HIPCHK(c, found.alloc(8));
     GLP_HIPCHK(c, hipMemcpyAsync(seed.p, h_seed4, 32, hipMemcpyHostToDevice, c->stream));
-    const u64 window = 1ull << 22;
+    // expected work is 2^pow_bits tries: search windows of 4x that (>= 2^16, <= 2^22 nonces per launch)
+    u64 window = 4ull << pow_bits;
+    if (window < (1ull << 16)) window = 1ull << 16;
+    if (window > (1ull << 22)) window = 1ull << 22;
     const GlpPoseidonConsts k = glp_dev_consts(c->hash);
     for (u64 base = 0; base < (1ull << 48); base += window) {
         unsigned long long init = ~0ull, got = 0;
