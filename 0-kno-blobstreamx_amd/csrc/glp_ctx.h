@@ -20,6 +20,7 @@ struct glp_ctx {
     int last_npass = 0;
     char err[512] = {0};
     std::map<int, glp_table> tables;     // key = log_N*2 + inv
+    std::map<int, u64*> full_tables;     // key = (log_N*64 + log_m)*2 + inv: per-element inter-pass twiddles
     std::map<uint32_t, std::string> plan_override;
     u64* scratch = nullptr;
     size_t scratch_bytes = 0;

@@ -125,6 +125,22 @@ struct HipBackend {
         if (ensure_table(c, log_N, inv) != GLP_OK) { rc = GLP_E_HIP; return nullptr; }
         return c->tables[log_N * 2 + (inv ? 1 : 0)].hi;
     }
+    const u64* table_full(int log_N, int log_m, int inv) {
+        if (getenv("GLP_NO_FULL_TW")) return nullptr;
+        const int key = (log_N * 64 + log_m) * 2 + (inv ? 1 : 0);
+        auto it = c->full_tables.find(key);
+        if (it != c->full_tables.end()) return it->second;
+        if (ensure_table(c, log_N, inv) != GLP_OK) { rc = GLP_E_HIP; return nullptr; }
+        const glp_table& t = c->tables[log_N * 2 + (inv ? 1 : 0)];
+        u64* d = nullptr;
+        if (hipMalloc((void**)&d, (size_t)8 << log_N) != hipSuccess) return nullptr;   // fall back to the running product
+        u64 blocks = ((1ull << log_N) + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(glp_build_full_tw_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, c->stream, d, (u32)log_N, (u32)log_m, t.lo, t.hi);
+        if (hipGetLastError() != hipSuccess) { hipFree(d); return nullptr; }
+        c->full_tables[key] = d;
+        return d;
+    }
     void mark(int idx) {
         if (c->profiling && idx < 2 * GLP_MAX_PASSES) hipEventRecord(c->pass_ev[idx], c->stream);
     }
@@ -192,6 +208,7 @@ extern "C" void glp_destroy(glp_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (auto& kv : c->tables) { if (kv.second.lo) hipFree(kv.second.lo); if (kv.second.hi) hipFree(kv.second.hi); }
+    for (auto& kv : c->full_tables) if (kv.second) hipFree(kv.second);
     if (c->shift_lo) hipFree(c->shift_lo);
     if (c->shift_hi) hipFree(c->shift_hi);
     if (c->scratch) hipFree(c->scratch);

@@ -5,6 +5,7 @@
 // Backend concept:
 //   const u64* table_lo(int log_N, int inv);   // device-visible tables (glp_fill_table)
 //   const u64* table_hi(int log_N, int inv);   // nullptr when log_N <= 12
+//   const u64* table_full(int log_N, int log_m, int inv);   // per-element inter-pass twiddles or nullptr
 //   int launch_pass(const GlpPass&, int inv, unsigned long long grid, unsigned block, size_t lds, const GlpNttPassArgs&);
 //   int launch_small(const u64* src, u64* dst, u64 ss, u64 ds, u32 log_n, u32 batch, const u64* tw, u64 scale, u32 rev);
 #pragma once
@@ -58,6 +59,9 @@ int glp_exec_ntt(Backend& be, const GlpPlan* pl, const GlpNttCall& c) {
         if (ps.mode == GLP_STRIP) {
             a.tw_lo = be.table_lo(log_N, c.inverse);
             a.tw_hi = be.table_hi(log_N, c.inverse);
+            // batched transforms of moderate size: one table multiply per element instead of the
+            // running product (the table tile is shared by all polynomials through L2)
+            if (c.batch >= GLP_FULL_TW_MIN_BATCH && log_N <= GLP_FULL_TW_MAX_LOG_N) a.tw_full = be.table_full(log_N, ps.log_m, c.inverse);
         }
         const int last = (i == pl->npass - 1);
         a.scale = last ? scale : 1ull;
@@ -77,6 +81,13 @@ int glp_exec_ntt(Backend& be, const GlpPlan* pl, const GlpNttCall& c) {
         if (ps.mode == GLP_STRIP && ps.log_c < 4 && ps.log_m >= 4) {
             const u32 g = 4u - (u32)ps.log_c;
             if (grid % (8ull << g) == 0) a.xcd_group_log = g;
+        }
+        a.poly_minor = (ps.mode == GLP_STRIP && a.tw_full && c.batch > 1) ? 1u : 0u;
+        if (a.poly_minor && a.xcd_group_log) {
+            // the pairing of line-sharing strips must survive the (position, polynomial) order:
+            // tiles per polynomial must be a multiple of the group
+            const unsigned long long tpp = 1ull << (c.log_n - ps.log_r - ps.log_c);
+            if (tpp % (1ull << a.xcd_group_log)) a.xcd_group_log = 0;
         }
         int rc = be.launch_pass(ps, c.inverse, grid, glp_pass_threads(&ps), glp_pass_lds_bytes(&ps), a);
         if (rc) return rc;

@@ -78,6 +78,8 @@ struct GlpNttPassArgs {
     u32 nprev;             // FINAL_T: number of earlier passes, and their log2 radices
     u32 log_rprev[3];
     u32 xcd_group_log;     // STRIP with C*8 < 128 B: log2 of strips sharing one 128-B line (0 = no remap)
+    const u64* tw_full;    // STRIP, optional: per-element inter-pass twiddles w_N^{j'k} at [k*m + j'] (batched sizes)
+    u32 poly_minor;        // STRIP: consecutive workgroups walk the polynomials of one tile position first
 };
 
 // LOG_E = log2 of the elements held per work-item (4: radix <= 16 steps, 5: radix <= 32 steps)
@@ -156,8 +158,20 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
     const u32 log_rows = a.log_n - LOG_R;    // rows per polynomial (FINAL modes)
     if constexpr (MODE == GLP_STRIP) {
         const u32 log_tpp = a.log_n - LOG_R - log_c;              // tiles per polynomial
-        const u64 poly = tile >> log_tpp;
-        const u32 t = (u32)(tile & ((1ull << log_tpp) - 1));
+        u64 poly;
+        u32 t;
+        if (a.poly_minor) {
+            // (tile position, polynomial) with the polynomial varying fastest, keeping the 2^g
+            // line-sharing strips adjacent: the per-element twiddle tile is then reused by
+            // `batch` consecutive workgroups out of L2
+            const u32 g = a.xcd_group_log;
+            const u64 rest = tile >> g;
+            poly = rest % a.batch;
+            t = (u32)(((rest / a.batch) << g) | (tile & ((1ull << g) - 1)));
+        } else {
+            poly = tile >> log_tpp;
+            t = (u32)(tile & ((1ull << log_tpp) - 1));
+        }
         const u32 log_mc = a.log_m - log_c;
         const u32 hi = t >> log_mc;
         lo0 = (t & ((1u << log_mc) - 1u)) << log_c;
@@ -262,7 +276,9 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                 // progression: two table look-ups (base, ratio) and a running product instead
                 // of 16 pairs of gathered loads.
                 u64 tw = 1, ratio = 1;
-                if constexpr (MODE == GLP_STRIP) {
+                const u64* twf = nullptr;
+                if constexpr (MODE == GLP_STRIP) twf = a.tw_full;
+                if (MODE == GLP_STRIP && !twf) {
                     const u32 log_N = LOG_R + a.log_m;
                     const u64 jq = (u64)(lo0 + col);
                     const u64 e0 = jq * glp_digit_reverse<LOG_R, LOG_E>(row0);      // < N <= 2^32
@@ -281,8 +297,12 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                     const u32 pos = row0 + (u32)d;                  // sigma == 1 in the last step
                     const u32 k = glp_digit_reverse<LOG_R, LOG_E>(pos);    // natural output index in [0,R)
                     if constexpr (MODE == GLP_STRIP) {
-                        v = gl_mul(v, tw);
-                        if constexpr (d + 1 < (int)r) tw = gl_mul(tw, ratio);
+                        if (twf) {
+                            v = gl_mul(v, twf[((u64)k << a.log_m) + lo0 + col]);
+                        } else {
+                            v = gl_mul(v, tw);
+                            if constexpr (d + 1 < (int)r) tw = gl_mul(tw, ratio);
+                        }
                         const u32 orow = a.rev ? glp_bitrev32(k, LOG_R) : k;
                         a.dst[dbase + ((u64)orow << a.log_m) + col] = v;
                     } else if constexpr (MODE == GLP_FINAL_T) {
@@ -336,5 +356,19 @@ __global__ void __launch_bounds__(256) glp_ntt_small_kernel(const u64* src, u64*
         if (scale != 1) acc = gl_mul(acc, scale);
         const u32 ko = rev ? glp_bitrev32(k, log_n) : k;
         dst[(u64)b * dst_poly_stride + ko] = acc;
+    }
+}
+
+// full[k*m + j'] = w_N^{j' * k},  N = R * m, k < R, j' < m  (built once per (N, m, direction))
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_build_full_tw_kernel(u64* __restrict__ full, u32 log_N, u32 log_m, const u64* __restrict__ tw_lo,
+                                                                const u64* __restrict__ tw_hi) {
+    const u64 N = 1ull << log_N;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        const u64 k = i >> log_m, j = i & ((1ull << log_m) - 1);
+        const u64 e = k * j;                                 // < N
+        u64 w = tw_lo[e & 4095u];
+        if (log_N > 12) w = gl_mul(w, tw_hi[e >> 12]);
+        full[i] = w;
     }
 }

@@ -11,6 +11,8 @@
 #define GLP_MAX_PASSES 4
 #define GLP_MIN_LOG_R 6     // smallest tile transform served by the pass kernel
 #define GLP_MAX_LOG_R 12
+#define GLP_FULL_TW_MIN_BATCH 8      // per-element inter-pass twiddle tables: batched transforms only
+#define GLP_FULL_TW_MAX_LOG_N 22     // ... and tables of at most 32 MiB
 #define GLP_TW_SPLIT 12     // two-level twiddle tables: w^e = lo[e & 4095] * hi[e >> 12]
 
 enum { GLP_STRIP = 0, GLP_FINAL_T = 1, GLP_FINAL_ROWS = 2 };   // pass kernel modes (ntt_kernels.cuh)

@@ -16,6 +16,20 @@ struct EmuBackend {
         auto& v = hi[log_N * 2 + inv];
         return v.empty() ? nullptr : v.data();
     }
+    std::map<int, std::vector<u64>> full;
+    const u64* table_full(int log_N, int log_m, int inv) {
+        const int key = (log_N * 64 + log_m) * 2 + inv;
+        if (!full.count(key)) {
+            ensure(log_N, inv);
+            auto& v = full[key];
+            v.resize((size_t)1 << log_N);
+            const u64* lo_p = lo[log_N * 2 + inv].data();
+            const u64* hi_p = hi[log_N * 2 + inv].empty() ? nullptr : hi[log_N * 2 + inv].data();
+            u64* out = v.data();
+            glp_emu_launch(4, 64, 0, [&] { glp_build_full_tw_kernel<0>(out, (u32)log_N, (u32)log_m, lo_p, hi_p); });
+        }
+        return full[key].data();
+    }
     void ensure(int log_N, int inv) {
         int key = log_N * 2 + inv;
         if (lo.count(key)) return;

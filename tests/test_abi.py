@@ -43,3 +43,17 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in txt and "orc_" not in txt and "oracle/" not in txt, os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c_and_links(pkg, tmp_path):
+    """include/glprover.h compiles as strict C99 and every symbol used links against the library"""
+    import subprocess
+    pkg.load_library()
+    exe = tmp_path / "abi_c99"
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "abi_c99.c"), "-o", str(exe), "-L", libdir, "-lglprover",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    assert "glprover" in r.stdout
