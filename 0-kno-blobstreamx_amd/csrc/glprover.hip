@@ -126,7 +126,10 @@ struct HipBackend {
         return c->tables[log_N * 2 + (inv ? 1 : 0)].hi;
     }
     const u64* table_full(int log_N, int log_m, int inv) {
-        if (getenv("GLP_NO_FULL_TW")) return nullptr;
+        // Measured on MI355X (profiles/r01_ntt_full_table_ab.txt): the per-element table makes the
+        // 128 x 2^20 strip pass SLOWER (0.967 vs 0.842 ms): the extra 8 B/element of L2 traffic costs
+        // more than the 15 multiplies it removes.  Kept as an opt-in experiment only.
+        if (!getenv("GLP_FULL_TW")) return nullptr;
         const int key = (log_N * 64 + log_m) * 2 + (inv ? 1 : 0);
         auto it = c->full_tables.find(key);
         if (it != c->full_tables.end()) return it->second;
