@@ -43,8 +43,8 @@ def pmc_traffic_bytes(plan_desc, elements):
         return None
     mode_id = {"strip": 0, "finalT": 1, "finalRows": 2}
     total = 0.0
-    for mode, lr, lc in re.findall(r"(strip|finalT|finalRows)\(R=2\^(\d+),C=2\^(\d+)\)", plan_desc):
-        key = f"void glp_ntt_pass_kernel<{lr}, {mode_id[mode]}, false>(GlpNttPassArgs)"
+    for mode, lr, lc, e32 in re.findall(r"(strip|finalT|finalRows)\(R=2\^(\d+),C=2\^(\d+)(,E=32)?\)", plan_desc):
+        key = f"void glp_ntt_pass_kernel<{lr}, {mode_id[mode]}, false, {5 if e32 else 4}>(GlpNttPassArgs)"
         ent = t.get(key)
         if not ent or ent.get("log_c") not in (None, int(lc)):
             return None
