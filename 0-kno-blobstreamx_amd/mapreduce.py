@@ -68,3 +68,16 @@ def allgather_leaf_proofs(local_blobs, n_leaves, padded_len, device=None):
     if missing:
         raise ValueError(f"leaf proofs missing after all-gather: {missing[:8]}")
     return proofs
+
+
+def map_prove_gather(prove_leaf, n_leaves, padded_len, device=None):
+    """The Map + exchange steps of a MapReduce proof: this rank proves leaves
+    ``leaves_of_rank(n_leaves, rank, world)`` with ``prove_leaf(i) -> bytes`` (e.g.
+    ``PlonkCircuit.prove`` of the leaf circuit on leaf i's witness), then every rank receives all
+    proofs in leaf order through ONE all-gather.  The Reduce step upstream is a tree of recursive
+    verifier circuits; in this build the gathered proofs are checked by the host-side verifier
+    (no in-circuit recursion yet — DESIGN.md §7), so what is returned is the ordered proof list."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine = [(i, prove_leaf(i)) for i in leaves_of_rank(n_leaves, rank, world)]
+    return allgather_leaf_proofs(mine, n_leaves, padded_len, device=device)

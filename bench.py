@@ -270,6 +270,55 @@ def prove_bench(sizes, quiet=False):
     return out
 
 
+def mapreduce_bench(n_leaves=16, log_n=16, W=80):
+    """BASELINE configs[2]/[3] shape (skip / batch leaves): Map = one leaf proof per leaf, leaf i on
+    rank i % world; exchange = one all-gather of padded proofs (RCCL when launched under
+    torch.distributed.run, a no-op on one rank).  Leaf circuit = the build-defined circuit; the
+    recursive Reduce step is not built, so the time reported is map + gather."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    pkg = graft.load_package()
+    mr = importlib.import_module(graft.PKG_NAME + ".mapreduce")
+    pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    pr = pkg.Prover(local_rank)
+    rc, circ, diag = pc.default_constants()
+    pr.set_poseidon_constants(np.array(rc, dtype=np.uint64), np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64))
+    consts, sigmas, wires = synthetic_circuit(pr, log_n, W)
+    ck = pkg.PlonkCircuit(pr, consts, sigmas)
+    dw = pr.to_device(wires)
+    ck.prove_(dw, 28, 16)                                   # warm-up
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    proofs = mr.map_prove_gather(lambda i: ck.prove_(dw, 28, 16), n_leaves, padded_len=1 << 18,
+                                 device=torch.device("cuda", local_rank) if world > 1 else None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"stage": "mapreduce_map+gather", "n_leaves": n_leaves, "leaf_log_n": log_n, "leaf_wires": W, "n_gpus": world,
+                          "seconds": round(dt, 4), "leaf_proof_bytes": len(proofs[0]), "all_present": all(len(p) > 0 for p in proofs),
+                          "note": "leaf = build-defined circuit; recursive reduce not built"}), flush=True)
+    dw.free()
+    ck.free()
+    pr.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,6 +332,7 @@ def main():
     ap.add_argument("--sweep", action="store_true", help="tuning aid: time alternative pass plans and exit")
     ap.add_argument("--hash-bench", action="store_true", help="tuning aid: Poseidon / LDE / Merkle stage times and exit")
     ap.add_argument("--prove-bench", action="store_true", help="end-to-end prove time of the build-defined circuit and exit")
+    ap.add_argument("--mapreduce", action="store_true", help="map (leaf proofs sharded over ranks) + all-gather timing and exit")
     args = ap.parse_args()
 
     if args.sweep:
@@ -291,6 +341,8 @@ def main():
         return hash_bench()
     if args.prove_bench:
         return prove_bench([(14, 16), (16, 80), (20, 80)])
+    if args.mapreduce:
+        return mapreduce_bench()
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
