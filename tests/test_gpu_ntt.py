@@ -175,3 +175,20 @@ def test_full_size_properties(prover, pkg, log_n, batch):
         r = int(format(k, f"0{log_n}b")[::-1], 2)
         assert fb[r] == fx[0][k]
     d.free()
+
+
+@pytest.mark.parametrize("log_n,batch,inv,rev", [(22, 2, 0, 0), (24, 1, 0, 0), (24, 1, 1, 1), (23, 3, 0, 1)])
+def test_full_size_bit_exact_vs_fast_oracle(prover, oracle, pkg, log_n, batch, inv, rev):
+    """BASELINE sizes bit-for-bit: the hand-reduced CPU transform (oracle/gl_fast.c, itself pinned to
+    the naive oracle and the golden vectors by tests/test_oracle.py) is fast enough to check 2^24"""
+    rng = np.random.default_rng(log_n * 7 + batch)
+    x = rand_field(rng, (batch, 1 << log_n))
+    ref = x.copy()
+    oracle.orc_ntt_fast(ptr(ref), log_n, batch, inv)
+    if rev:
+        oracle.orc_bitrev_rows(ptr(ref), log_n, batch)
+    d = prover.to_device(x)
+    prover.ntt_ex(d, d, log_n, batch, flags=inv * pkg.NTT_INVERSE + rev * pkg.NTT_BITREV)
+    got = d.download(x.shape)
+    d.free()
+    assert np.array_equal(got, ref)
