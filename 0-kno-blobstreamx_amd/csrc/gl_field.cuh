@@ -77,6 +77,25 @@ GL_HD u64 gl_mul(u64 a, u64 b) {
 }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 
+// "nc" = not canonicalised: inputs may be ANY u64 representative, the result is a correct
+// representative in [0, 2^64) that may be >= p.  Saves the (r >= p) compare of every product in
+// long multiplication chains whose end result is canonicalised once (Poseidon S-boxes).
+GL_HD u64 gl_mul_nc(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p0 = (u64)a0 * b0;
+    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
+    const u64 p2 = (u64)a1 * b0 + (u32)p1;
+    const u64 hi = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32), lo = (p2 << 32) | (u32)p0;
+    const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+    u64 t0;
+    const bool bor = __builtin_sub_overflow(lo, (u64)h1, &t0);
+    t0 = bor ? t0 + GL_P : t0;
+    const u64 t1 = ((u64)h0 << 32) - h0;
+    u64 r;
+    const bool c = __builtin_add_overflow(t0, t1, &r);
+    return r + (c ? GL_EPS : 0ULL);               // carry: r < t1 <= 2^64 - 2^33 + 1, no second overflow
+}
+
 // ---- multiplication by powers of two (the twiddles of every radix <= 64 butterfly) ------
 // x * 2^T, 0 < T < 32:  (x << T) + (x >> (64-T)) * (2^32 - 1)
 template <int T>

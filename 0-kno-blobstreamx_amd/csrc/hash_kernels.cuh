@@ -41,9 +41,11 @@ struct GlpPoseidonConsts {
 
 #define glp_hfor glp_static_for
 
+// x^7.  Inside a permutation values are kept as arbitrary u64 representatives (products and MDS
+// rows skip the ">= p" check); glp_poseidon_permute canonicalises its 12 outputs once.
 GL_HD u64 glp_sbox7(u64 x) {
-    u64 x2 = gl_mul(x, x), x3 = gl_mul(x2, x), x4 = gl_mul(x2, x2);
-    return gl_mul(x3, x4);
+    u64 x2 = gl_mul_nc(x, x), x3 = gl_mul_nc(x2, x), x4 = gl_mul_nc(x2, x2);
+    return gl_mul_nc(x3, x4);
 }
 
 // s <- MDS * s (+ rc_next)  with  row r = sum_i s[(i + r) % 12] * circ[i] + s[r] * diag[r].
@@ -78,9 +80,10 @@ GL_HD void glp_mds_layer(u64 (&s)[12], const u64* __restrict__ circ, const u64* 
             const u64 t = (ah >> 32) * GL_EPS;
             const u64 v = l + t;
             const bool c2 = v < l;
-            out[r] = v + ((c1 | c2 | (v >= GL_P)) ? GL_EPS : 0ULL);
+            out[r] = v + ((c1 | c2) ? GL_EPS : 0ULL);   // representative in [0, 2^64), canonicalised at the end
         });
     } else {
+        glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = gl_canon(s[i]); });   // S-box outputs are not canonical
         glp_hfor<0, 12>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
             u64 acc = gl_mul(s[r], diag[r]);
@@ -110,7 +113,7 @@ GL_HD u64 glp_dot_small(const u32 (&lo)[N], const u32 (&hi)[N], const u32* __res
     const u64 t = (ah >> 32) * GL_EPS;
     const u64 v = l + t;
     const bool c2 = v < l;
-    return v + ((c1 | c2 | (v >= GL_P)) ? GL_EPS : 0ULL);
+    return v + ((c1 | c2) ? GL_EPS : 0ULL);        // representative in [0, 2^64), not canonicalised
 }
 
 // Three consecutive partial rounds at once.  Only lane 0 is non-linear, so the state before
@@ -163,6 +166,7 @@ GL_HD void glp_poseidon_permute(u64 (&s)[12], const GlpPoseidonConsts& k) {
         glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = glp_sbox7(s[i]); });
         glp_mds_layer<SMALL>(s, k.circ, k.diag, rnd + 1 < GLP_POS_ROUNDS ? k.rc + (rnd + 1) * 12 : nullptr);
     }
+    glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = gl_canon(s[i]); });
 }
 
 // n independent permutations, in place, states [n][12]
