@@ -270,7 +270,7 @@ def prove_bench(sizes, quiet=False):
     return out
 
 
-def mapreduce_bench(n_leaves=16, log_n=16, W=80):
+def mapreduce_bench(leaves_per_rank=16, log_n=16, W=80):
     """BASELINE configs[2]/[3] shape (skip / batch leaves): Map = one leaf proof per leaf, leaf i on
     rank i % world; exchange = one all-gather of padded proofs (RCCL when launched under
     torch.distributed.run, a no-op on one rank).  Leaf circuit = the build-defined circuit; the
@@ -281,6 +281,7 @@ def mapreduce_bench(n_leaves=16, log_n=16, W=80):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_leaves = leaves_per_rank * world                     # skip=1024 / batch=8 -> 128 leaves on 8 GPUs
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

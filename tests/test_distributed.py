@@ -30,6 +30,8 @@ def _worker(rank, world, port, n_leaves, q):
     local = [(i, fake_proof(i)) for i in mine]
     proofs = mr.allgather_leaf_proofs(local, n_leaves, padded_len=200)
     ok = proofs == [fake_proof(i) for i in range(n_leaves)]
+    # the map + exchange wrapper used by bench.py --mapreduce (prove_leaf stands in for PlonkCircuit.prove)
+    ok = ok and mr.map_prove_gather(fake_proof, n_leaves, padded_len=200) == proofs
     # the bench's max-over-ranks time reduction
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
