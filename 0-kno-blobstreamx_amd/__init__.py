@@ -84,6 +84,8 @@ def load_library():
                                                  ctypes.c_size_t]),
         "glp_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
         "glp_last_pass_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
+        "glp_last_stage_ms": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_float),
+                                             ctypes.POINTER(ctypes.c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -265,6 +267,15 @@ class Prover:
         n = ctypes.c_int()
         self._chk(self.lib.glp_last_pass_ms(self.ctx, ms, ctypes.byref(n)), "glp_last_pass_ms")
         return [ms[i] for i in range(n.value)]
+
+    def last_stage_ms(self):
+        """[(stage name, ms)] of the last prove while profiling was on"""
+        names = ctypes.create_string_buffer(2048)
+        ms = (ctypes.c_float * 32)()
+        n = ctypes.c_int(32)
+        self._chk(self.lib.glp_last_stage_ms(self.ctx, names, 2048, ms, ctypes.byref(n)), "glp_last_stage_ms")
+        ns = names.value.decode().split(";") if n.value else []
+        return [(ns[i], round(ms[i], 3)) for i in range(n.value)]
 
     # ---- numpy in / numpy out (upstream names, recalled: plonky2_field::fft) -----------
     def _xform(self, x, flags):

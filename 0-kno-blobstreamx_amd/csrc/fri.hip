@@ -218,6 +218,7 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
     for (u32 b = 0; b < n_batches; b++)
         for (u32 i = 0; i < (4u << cap0); i++) { const u64 v = batches[b].h_cap[i]; if (v >= GL_P) { glp_set_err(c, "cap not canonical"); return GLP_E_INVALID; } put(v); ch.observe(v); }
 
+    glp_stage_mark(c, "fri:evaluate_openings");
     // opening points z_p = zeta * mult_p and the openings, in (point, batch, polynomial) order
     const gl_ext2 zeta = ch.ext_challenge();
     std::vector<u64> openings(2 * (size_t)total_polys);
@@ -239,6 +240,7 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
     for (u64 v : openings) { put(v); ch.observe(v); }
     const gl_ext2 alpha = ch.ext_challenge();
 
+    glp_stage_mark(c, "fri:combine");
     // alpha powers (one per opening) ; per point Y_p = sum alpha^k y_k over that point's openings
     std::vector<u64> apow(2 * (size_t)total_polys);
     {
@@ -289,6 +291,7 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
         }
     }
 
+    glp_stage_mark(c, "fri:fold_layers+merkle");
     // commit phase: L layers of arity 2^a
     struct Layer { DevBuf code, dig; u32 log_len; u32 cap_h; };
     std::vector<std::unique_ptr<Layer>> layers;
@@ -354,6 +357,7 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
         for (u64 j = 0; j < (1ull << final_bits); j++) { put(co[j].a); put(co[j].b); ch.observe_ext(co[j]); }
     }
 
+    glp_stage_mark(c, "fri:proof_of_work");
     // proof of work
     {
         u64 seed[4];
@@ -365,6 +369,7 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
         ch.observe(nonce % GL_P);
     }
 
+    glp_stage_mark(c, "fri:queries");
     // query phase
     std::vector<u64> idx(cfg->num_queries);
     for (u32 q = 0; q < cfg->num_queries; q++) idx[q] = ch.challenge() & (N - 1);
@@ -450,8 +455,10 @@ extern "C" int glp_fri_prove(glp_ctx* c, const glp_fri_config* cfg, const glp_fr
     if (!chp) return GLP_E_STATE;
     std::unique_ptr<glp_challenger> guard(chp);
     std::vector<u64> P;
+    c->stages.clear(); c->stage_name.clear();
     int rc = glp_fri_prove_impl(c, cfg, batches, n_batches, *chp, P);
     if (rc) return rc;
+    glp_stage_mark(c, nullptr);
     *proof_out = glp_words_to_blob(P, proof_len);
     return *proof_out ? GLP_OK : GLP_E_NOMEM;
 }

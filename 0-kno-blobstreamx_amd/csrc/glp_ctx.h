@@ -1,8 +1,11 @@
 // glp_ctx.h — the opaque context behind include/glprover.h (internal to libglprover.so).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <map>
 #include <string>
+#include <utility>
+#include <vector>
 #include "../../include/glprover.h"
 #include "gl_field.cuh"
 #include "ntt_plan.h"
@@ -30,7 +33,23 @@ struct glp_ctx {
     u64 shift_val = 0;
     int shift_log_n = -1;
     glp_hash_state* hash = nullptr;      // Poseidon constants etc. (hash.hip)
+    // prover stage timers (filled only while profiling is on: each mark synchronises the stream)
+    std::vector<std::pair<std::string, float>> stages;
+    std::chrono::steady_clock::time_point stage_t0;
+    std::string stage_name;
 };
+
+// stage timing tree of the prover drivers (the TimingTree of the upstream prover, recalled): a
+// mark closes the running stage and opens the next; no-ops unless glp_set_profiling(ctx, 1)
+static inline void glp_stage_mark(glp_ctx* c, const char* next_name) {
+    if (!c->profiling) return;
+    hipStreamSynchronize(c->stream);
+    const auto now = std::chrono::steady_clock::now();
+    if (!c->stage_name.empty())
+        c->stages.emplace_back(c->stage_name, std::chrono::duration<float, std::milli>(now - c->stage_t0).count());
+    c->stage_name = next_name ? next_name : "";
+    c->stage_t0 = now;
+}
 
 void glp_set_err(glp_ctx* c, const char* fmt, ...);
 void glp_hash_destroy(glp_ctx* c);

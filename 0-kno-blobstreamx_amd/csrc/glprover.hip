@@ -318,6 +318,22 @@ extern "C" int glp_set_profiling(glp_ctx* c, int on) {
     c->last_npass = 0;
     return GLP_OK;
 }
+extern "C" int glp_last_stage_ms(glp_ctx* c, char* names, size_t names_len, float* ms, int* n_inout) {
+    if (!c || !names || !ms || !n_inout || names_len == 0) return GLP_E_INVALID;
+    const int cap = *n_inout;
+    size_t off = 0;
+    int k = 0;
+    names[0] = 0;
+    for (const auto& st : c->stages) {
+        if (k >= cap) break;
+        const int w = snprintf(names + off, names_len - off, "%s%s", k ? ";" : "", st.first.c_str());
+        if (w < 0 || (size_t)w >= names_len - off) break;
+        off += (size_t)w;
+        ms[k++] = st.second;
+    }
+    *n_inout = k;
+    return GLP_OK;
+}
 extern "C" int glp_last_pass_ms(glp_ctx* c, float* ms, int* n_out) {
     if (!c || !ms || !n_out) return GLP_E_INVALID;
     *n_out = 0;

@@ -128,6 +128,8 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
     put(0x31304B4C504C4747ull /* "GGLPLK01" */); put(log_n); put(W); put(rb); put(ck->cap_h);
     for (u64 v : ck->pre.cap) put(v);
 
+    c->stages.clear(); c->stage_name.clear();
+    glp_stage_mark(c, "commit_wires(ifft+lde+merkle)");
     // ---- wires ----------------------------------------------------------------------------
     Commit wires;
     {
@@ -142,6 +144,7 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) beta[t] = ch.challenge();
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) gamma[t] = ch.challenge();
 
+    glp_stage_mark(c, "perm_products(K6)");
     // ---- K6: Z and partial products on the trace domain --------------------------------------
     const u64* wn_lo = nullptr; const u64* wn_hi = nullptr;
     int rc = glp_ntt_table(c, (int)log_n, 0, &wn_lo, &wn_hi);
@@ -170,11 +173,13 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
         GLP_HIPCHK(c, hipGetLastError());
     }
     zs.coeffs.p = nullptr;
+    glp_stage_mark(c, "commit_zs");
     rc = commit_values(c, zs_vals, GLP_PLONK_NCHAL * M, log_n, rb, ck->cap_h, zs);
     if (rc) return rc;
     for (u64 v : zs.cap) put(v);
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) alpha[t] = ch.challenge();
 
+    glp_stage_mark(c, "quotient(K7)+to_coeffs");
     // ---- K7: quotient on the LDE domain --------------------------------------------------------
     const u32 n_con = 1 + 3 * M;
     std::vector<u64> apow((size_t)GLP_PLONK_NCHAL * n_con);
@@ -229,6 +234,7 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
         GLP_HIPCHK(c, hipGetLastError());
         GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    glp_stage_mark(c, "commit_quotient(lde+merkle)");
     // each quotient has 8n coefficients = 8 chunks of n: [NCHAL][8][n] is already a dense
     // batch of 16 coefficient-form polynomials
     {
@@ -259,6 +265,7 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
     }
     rc = glp_fri_prove_impl(c, &fc, fb, 4, ch, P);
     if (rc) return rc;
+    glp_stage_mark(c, nullptr);
     *proof_out = glp_words_to_blob(P, proof_len);
     return *proof_out ? GLP_OK : GLP_E_NOMEM;
 }

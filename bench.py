@@ -258,7 +258,11 @@ def prove_bench(sizes, quiet=False):
             ta = time.perf_counter()
             proof = ck.prove_(dw, 28, 16)
             times.append(time.perf_counter() - ta)
-        res = {"stage": "plonk_prove", "circuit": "build-defined arithmetic+permutation circuit (DESIGN.md 3.6), NOT upstream's",
+        pr.set_profiling(True)                                   # one more proof with stage marks (adds syncs)
+        ck.prove_(dw, 28, 16)
+        stages = pr.last_stage_ms()
+        pr.set_profiling(False)
+        res = {"stage": "plonk_prove", "stage_ms": dict(stages), "circuit": "build-defined arithmetic+permutation circuit (DESIGN.md 3.6), NOT upstream's",
                "log_n": log_n, "wires": W, "setup_s_incl_h2d": round(t1 - t0, 3), "prove_s": [round(t, 4) for t in times],
                "prove_s_best": round(min(times), 4), "proof_bytes": len(proof), "queries": 28, "pow_bits": 16}
         if not quiet:
@@ -438,7 +442,8 @@ def main():
         # the build's own 2^20-row circuit (configs[1] size); the upstream circuits are not in the mount
         r = prove_bench([(20, 80)], quiet=True)[0]
         out["prove"] = {"seconds": r["prove_s_best"], "circuit": r["circuit"], "log_n": 20, "wires": 80, "proof_bytes": r["proof_bytes"],
-                        "queries": 28, "pow_bits": 16, "note": "commit wires, Z/partial products, quotient, FRI openings; inputs resident in HBM"}
+                        "queries": 28, "pow_bits": 16, "stage_ms": r["stage_ms"],
+                        "note": "commit wires, Z/partial products, quotient, FRI openings; inputs resident in HBM"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

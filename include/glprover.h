@@ -85,6 +85,9 @@ int glp_ntt_describe_plan(glp_ctx* ctx, uint32_t log_n, uint32_t batch, uint32_t
 /* per-pass kernel times (ms) of the LAST glp_ntt*_ call when profiling is on; n_out <= 4 */
 int glp_set_profiling(glp_ctx* ctx, int on);
 int glp_last_pass_ms(glp_ctx* ctx, float* ms, int* n_out);
+/* stage timing tree of the LAST glp_plonk_prove / glp_fri_prove while profiling is on (each stage
+ * boundary then synchronises the stream): names are ';'-separated, *n_inout = capacity in, count out */
+int glp_last_stage_ms(glp_ctx* ctx, char* names, size_t names_len, float* ms, int* n_inout);
 
 /* ---- Poseidon / Merkle (row a4; upstream names recalled: plonky2::hash::poseidon,
  *      hashing::hash_n_to_hash_no_pad, PoseidonHash::two_to_one, merkle_tree::MerkleTree::new) */

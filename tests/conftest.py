@@ -94,8 +94,11 @@ def pkg():
 @pytest.fixture(scope="session")
 def emu():
     d = os.path.join(ROOT, "tests", "emu")
-    subprocess.run(["make", "-s"], cwd=d, check=True)
-    lib = ctypes.CDLL(os.path.join(d, "libglp_emu.so"))
+    # GLP_EMU_ASAN=1 (with LD_PRELOAD=libasan.so, ASAN_OPTIONS=detect_leaks=0): run the kernel bodies
+    # under AddressSanitizer + UBSan — the sanitizer leg of the CPU build (GPU ASan is not available)
+    asan = os.environ.get("GLP_EMU_ASAN") == "1"
+    subprocess.run(["make", "-s"] + (["asan"] if asan else []), cwd=d, check=True)
+    lib = ctypes.CDLL(os.path.join(d, "libglp_emu_asan.so" if asan else "libglp_emu.so"))
     lib.emu_ntt.argtypes = [u64p, u64p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint, ctypes.c_int,
                             ctypes.c_int, ctypes.c_char_p]
     for name in ("emu_gl_add", "emu_gl_sub", "emu_gl_mul", "emu_gl_reduce128"):

@@ -78,3 +78,23 @@ def test_tampered_plonk_proof_rejected(setup, pkg):
         with pytest.raises(Exception):
             pref.verify_plonk(bad.tobytes(), oracle)
     ck.free()
+
+
+def test_stage_timing_tree(setup, pkg):
+    prover, oracle = setup
+    rng = np.random.default_rng(3)
+    circ = pref.build_circuit(rng, 9, 16)
+    ck = pkg.PlonkCircuit(prover, circ["consts"], circ["sigmas"])
+    prover.set_profiling(True)
+    proof = ck.prove(circ["wires"], 8, 4)
+    stages = prover.last_stage_ms()
+    prover.set_profiling(False)
+    pref.verify_plonk(proof, oracle)
+    names = [n for n, _ in stages]
+    assert names[:5] == ["commit_wires(ifft+lde+merkle)", "perm_products(K6)", "commit_zs", "quotient(K7)+to_coeffs",
+                         "commit_quotient(lde+merkle)"]
+    assert [n for n in names if n.startswith("fri:")] == ["fri:evaluate_openings", "fri:combine", "fri:fold_layers+merkle",
+                                                          "fri:proof_of_work", "fri:queries"]
+    assert all(ms >= 0 for _, ms in stages)
+    assert prover.last_stage_ms() == stages          # stable until the next prove
+    ck.free()
