@@ -69,6 +69,7 @@ def load_library():
         "glp_h2d": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
         "glp_d2h": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
         "glp_sync": (ctypes.c_int, [_vp]),
+        "glp_trim_pool": (ctypes.c_int, [_vp]),
         "glp_set_stream": (ctypes.c_int, [_vp, _vp]),
         "glp_timer_start": (ctypes.c_int, [_vp]),
         "glp_timer_stop": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
@@ -174,6 +175,7 @@ class Prover:
     def __init__(self, device=0):
         self.lib = load_library()
         self._bufs = set()
+        self._circuits = []
         ctx = _vp()
         rc = self.lib.glp_create(ctypes.byref(ctx), int(device))
         if rc != 0:
@@ -182,6 +184,8 @@ class Prover:
 
     def close(self):
         if getattr(self, "ctx", None):
+            for ck in list(self._circuits):      # circuits hold pool blocks of this ctx: free them first
+                ck.free()
             for b in list(self._bufs):
                 b.free()
             self.lib.glp_destroy(self.ctx)
@@ -525,6 +529,7 @@ class PlonkCircuit:
         prover._chk(prover.lib.glp_plonk_setup(prover.ctx, self.log_n, self.n_wires, dc.ptr, ds.ptr, rate_bits, cap_height,
                                                ctypes.byref(h)), "glp_plonk_setup")
         self.h = h
+        prover._circuits.append(self)
         dc.free()
         ds.free()
 
@@ -548,8 +553,11 @@ class PlonkCircuit:
 
     def free(self):
         if getattr(self, "h", None):
-            self.prover.lib.glp_plonk_free(self.h)
+            if getattr(self.prover, "ctx", None):        # after glp_destroy the pool (and the blocks) are gone
+                self.prover.lib.glp_plonk_free(self.h)
             self.h = None
+            if self in self.prover._circuits:
+                self.prover._circuits.remove(self)
 
     def __del__(self):
         try:

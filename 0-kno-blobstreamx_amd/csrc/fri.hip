@@ -54,18 +54,13 @@ extern "C" void glp_free_host(void* p) { free(p); }
 // helpers
 // ---------------------------------------------------------------------------------------
 namespace {
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-    u64* u() const { return (u64*)p; }
-};
+typedef GlpPoolBuf DevBuf;   // temporaries come from the ctx pool (glp_ctx.h): no hipMalloc/hipFree per proof
 
 // f_p(z) for every polynomial of one batch -> out[2*p], out[2*p+1]
 int eval_batch_at(glp_ctx* c, const u64* d_coeffs, u64 stride, u32 log_n, u32 n_polys, const u64* d_zp, u64* h_out) {
     const u64 n = 1ull << log_n;
     const u32 n_chunks = (u32)((n + GLP_EVAL_CHUNK - 1) / GLP_EVAL_CHUNK);
-    DevBuf part;
+    DevBuf part(c);
     GLP_HIPCHK(c, part.alloc((size_t)n_polys * n_chunks * 16));
     hipLaunchKernelGGL(glp_eval_ext_kernel<0>, dim3(n_polys * n_chunks), dim3(256), 0, c->stream, d_coeffs, stride, n, n_chunks, d_zp,
                        part.u());
@@ -91,7 +86,7 @@ int build_zpowers(glp_ctx* c, gl_ext2 z, u32 log_n, DevBuf& zp) {
     const gl_ext2 z256 = t;
     t = gl_ext2{1, 0};
     for (u64 j = 0; j < nhi; j++) { hi[2 * j] = t.a; hi[2 * j + 1] = t.b; t = gl_ext_mul(t, z256); }
-    DevBuf dlo, dhi;
+    DevBuf dlo(c), dhi(c);
     GLP_HIPCHK(c, dlo.alloc(lo.size() * 8));
     GLP_HIPCHK(c, dhi.alloc(hi.size() * 8));
     GLP_HIPCHK(c, hipMemcpyAsync(dlo.p, lo.data(), lo.size() * 8, hipMemcpyHostToDevice, c->stream));
@@ -109,7 +104,7 @@ u64 digest_level_base(u64 n_leaves, u32 h) { return h == 0 ? 0 : 4 * (2 * n_leav
 
 int gather(glp_ctx* c, const u64* d_src, const std::vector<u64>& offs, u64* h_out) {
     if (offs.empty()) return GLP_OK;
-    DevBuf doffs, dout;
+    DevBuf doffs(c), dout(c);
     GLP_HIPCHK(c, doffs.alloc(offs.size() * 8));
     GLP_HIPCHK(c, dout.alloc(offs.size() * 8));
     GLP_HIPCHK(c, hipMemcpyAsync(doffs.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, c->stream));
@@ -130,7 +125,7 @@ extern "C" int glp_eval_at_ext(glp_ctx* c, const uint64_t* d_coeffs, uint64_t po
         return GLP_E_INVALID;
     }
     if (n_polys == 0) return GLP_OK;
-    DevBuf zp;
+    DevBuf zp(c);
     int rc = build_zpowers(c, gl_ext2{h_z[0], h_z[1]}, log_n, zp);
     if (rc) return rc;
     return eval_batch_at(c, d_coeffs, poly_stride, log_n, n_polys, zp.u(), h_out);
@@ -141,7 +136,7 @@ extern "C" int glp_pow_grind(glp_ctx* c, const uint64_t* h_seed4, uint32_t pow_b
     if (!h_seed4 || !h_nonce || pow_bits > 40) { glp_set_err(c, "glp_pow_grind: bad argument"); return GLP_E_INVALID; }
     if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set"); return GLP_E_STATE; }
     if (pow_bits == 0) { *h_nonce = 0; return GLP_OK; }
-    DevBuf seed, found;
+    DevBuf seed(c), found(c);
     GLP_HIPCHK(c, seed.alloc(32));
     GLP_HIPCHK(c, found.alloc(8));
     GLP_HIPCHK(c, hipMemcpyAsync(seed.p, h_seed4, 32, hipMemcpyHostToDevice, c->stream));
@@ -226,7 +221,7 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
     {
         size_t off = 0;
         for (u32 p = 0; p < NP; p++) {
-            DevBuf zp;
+            DevBuf zp(c);
             rc = build_zpowers(c, gl_ext_scale(zeta, cfg->point_mult[p]), log_n, zp);
             if (rc) return rc;
             for (u32 b = 0; b < n_batches; b++) {
@@ -247,7 +242,7 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
         gl_ext2 t{1, 0};
         for (u32 k = 0; k < total_polys; k++) { apow[2 * k] = t.a; apow[2 * k + 1] = t.b; t = gl_ext_mul(t, alpha); }
     }
-    DevBuf d_apow, d_code, d_tmp;
+    DevBuf d_apow(c), d_code(c), d_tmp(c);
     GLP_HIPCHK(c, d_apow.alloc(apow.size() * 8));
     GLP_HIPCHK(c, hipMemcpyAsync(d_apow.p, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, c->stream));
     GLP_HIPCHK(c, d_code.alloc(N * 16));
@@ -293,13 +288,13 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
 
     glp_stage_mark(c, "fri:fold_layers+merkle");
     // commit phase: L layers of arity 2^a
-    struct Layer { DevBuf code, dig; u32 log_len; u32 cap_h; };
+    struct Layer { DevBuf code, dig; u32 log_len; u32 cap_h; explicit Layer(glp_ctx* cx) : code(cx), dig(cx), log_len(0), cap_h(0) {} };
     std::vector<std::unique_ptr<Layer>> layers;
-    DevBuf cur; cur.p = d_code.p; d_code.p = nullptr;       // take ownership
+    DevBuf cur(c); cur.adopt(d_code.release());             // take ownership
     u32 log_len = log_N;
     u64 shift = cfg->shift;
     for (u32 l = 0; l < L; l++) {
-        std::unique_ptr<Layer> ly(new Layer());
+        std::unique_ptr<Layer> ly(new Layer(c));
         ly->log_len = log_len;
         const u32 log_leaves = log_len - a;
         ly->cap_h = cfg->cap_height < log_leaves ? cfg->cap_height : log_leaves;
@@ -309,11 +304,11 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
         if (rc) return rc;
         for (u64 v : cap) { put(v); ch.observe(v); }
         gl_ext2 beta = ch.ext_challenge();
-        DevBuf src; src.p = cur.p; cur.p = nullptr;
+        DevBuf src(c); src.adopt(cur.release());
         const u64* in = (const u64*)src.p;
         std::vector<std::unique_ptr<DevBuf>> tmp;
         for (u32 f = 0; f < a; f++) {
-            std::unique_ptr<DevBuf> o(new DevBuf());
+            std::unique_ptr<DevBuf> o(new DevBuf(c));
             GLP_HIPCHK(c, o->alloc((size_t)16 << (log_len - 1)));
             const u64 hb[2] = {beta.a, beta.b};
             rc = glp_fri_fold2(c, in, o->u(), log_len, shift, hb);
@@ -324,9 +319,8 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
             shift = gl_mul(shift, shift);
             log_len--;
         }
-        GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
-        cur.p = tmp.back()->p; tmp.back()->p = nullptr;     // keep the last, free the intermediates
-        ly->code.p = src.p; src.p = nullptr;
+        cur.adopt(tmp.back()->release());                   // keep the last; intermediates go back to the pool
+        ly->code.adopt(src.release());
         layers.push_back(std::move(ly));
     }
 

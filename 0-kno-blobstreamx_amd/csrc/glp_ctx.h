@@ -33,6 +33,12 @@ struct glp_ctx {
     u64 shift_val = 0;
     int shift_log_n = -1;
     glp_hash_state* hash = nullptr;      // Poseidon constants etc. (hash.hip)
+    // device-memory pool for the prover drivers' temporaries: hipMalloc/hipFree cost milliseconds and
+    // hipFree synchronises; all work of a ctx is ordered on one stream, so a block released by the host
+    // can be handed to later work of the same stream without waiting (stream-ordered reuse).
+    std::multimap<size_t, void*> pool_free;      // size -> block
+    std::map<void*, size_t> pool_live;           // block -> size
+    size_t pool_cached_bytes = 0;
     // prover stage timers (filled only while profiling is on: each mark synchronises the stream)
     std::vector<std::pair<std::string, float>> stages;
     std::chrono::steady_clock::time_point stage_t0;
@@ -52,6 +58,25 @@ static inline void glp_stage_mark(glp_ctx* c, const char* next_name) {
 }
 
 void glp_set_err(glp_ctx* c, const char* fmt, ...);
+void* glp_pool_alloc(glp_ctx* c, size_t bytes);          // nullptr on failure (error text set)
+void glp_pool_release(glp_ctx* c, void* p);              // back to the pool (no hipFree, no sync)
+void glp_pool_trim(glp_ctx* c);                          // hipFree every cached block
+
+// RAII block from the ctx pool
+struct GlpPoolBuf {
+    glp_ctx* c = nullptr;
+    void* p = nullptr;
+    GlpPoolBuf() {}
+    explicit GlpPoolBuf(glp_ctx* ctx) : c(ctx) {}
+    GlpPoolBuf(const GlpPoolBuf&) = delete;
+    GlpPoolBuf& operator=(const GlpPoolBuf&) = delete;
+    ~GlpPoolBuf() { reset(); }
+    void reset() { if (p && c) glp_pool_release(c, p); p = nullptr; }
+    hipError_t alloc(size_t bytes) { reset(); p = glp_pool_alloc(c, bytes); return p ? hipSuccess : hipErrorOutOfMemory; }
+    void adopt(void* q) { reset(); p = q; }              // q must come from glp_pool_alloc of the same ctx
+    void* release() { void* q = p; p = nullptr; return q; }
+    u64* u() const { return (u64*)p; }
+};
 void glp_hash_destroy(glp_ctx* c);
 
 #define GLP_HIPCHK(c, expr)                                                                    \

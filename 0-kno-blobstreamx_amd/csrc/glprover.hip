@@ -21,6 +21,57 @@ void glp_set_err(glp_ctx* c, const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------------------------------
+// device-memory pool (glp_ctx.h)
+// ---------------------------------------------------------------------------------------
+static size_t pool_round(size_t bytes) {
+    const size_t g = bytes < (1u << 20) ? 4096 : (2u << 20);     // 4 KiB / 2 MiB granules
+    return ((bytes ? bytes : 1) + g - 1) / g * g;
+}
+void* glp_pool_alloc(glp_ctx* c, size_t bytes) {
+    const size_t sz = pool_round(bytes);
+    auto it = c->pool_free.lower_bound(sz);
+    if (it != c->pool_free.end() && it->first <= sz + sz / 8) {   // reuse a block at most 12.5 % larger
+        void* p = it->second;
+        c->pool_live[p] = it->first;
+        c->pool_cached_bytes -= it->first;
+        c->pool_free.erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+        glp_pool_trim(c);                                          // give cached blocks back and retry once
+        e = hipMalloc(&p, sz);
+    }
+    if (e != hipSuccess) { glp_set_err(c, "device allocation of %zu bytes failed: %s", sz, hipGetErrorString(e)); return nullptr; }
+    c->pool_live[p] = sz;
+    return p;
+}
+void glp_pool_release(glp_ctx* c, void* p) {
+    if (!p) return;
+    auto it = c->pool_live.find(p);
+    if (it == c->pool_live.end()) { hipFree(p); return; }          // not ours: plain free
+    c->pool_free.emplace(it->second, p);
+    c->pool_cached_bytes += it->second;
+    c->pool_live.erase(it);
+    const char* cap = getenv("GLP_POOL_CAP_MB");
+    const size_t limit = cap && atoll(cap) > 0 ? (size_t)atoll(cap) << 20 : (size_t)64 << 30;
+    if (c->pool_cached_bytes > limit) glp_pool_trim(c);
+}
+void glp_pool_trim(glp_ctx* c) {
+    if (c->pool_free.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pool_free) hipFree(kv.second);
+    c->pool_free.clear();
+    c->pool_cached_bytes = 0;
+}
+extern "C" int glp_trim_pool(glp_ctx* c) {
+    if (!c) return GLP_E_INVALID;
+    glp_pool_trim(c);
+    return GLP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------------------
 // out[b][j] = j < n ? coeffs[b][j] * shift^j : 0   (shift^j = s_lo[j & 4095] * s_hi[j >> 12])
@@ -215,6 +266,9 @@ extern "C" void glp_destroy(glp_ctx* c) {
     if (c->shift_lo) hipFree(c->shift_lo);
     if (c->shift_hi) hipFree(c->shift_hi);
     if (c->scratch) hipFree(c->scratch);
+    glp_pool_trim(c);
+    for (auto& kv : c->pool_live) hipFree(kv.first);             // blocks a driver still held (error paths)
+    c->pool_live.clear();
     glp_hash_destroy(c);
     hipEventDestroy(c->t0);
     hipEventDestroy(c->t1);

@@ -23,26 +23,23 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
 uint8_t* glp_words_to_blob(const std::vector<u64>& P, size_t* len);
 
 namespace {
-struct DBuf {
-    void* p = nullptr;
-    ~DBuf() { if (p) hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-    u64* u() const { return (u64*)p; }
-};
+typedef GlpPoolBuf DBuf;     // ctx pool blocks (glp_ctx.h)
 struct Commit {                 // one PolynomialBatch kept on the device
     DBuf coeffs, lde, dig;
     std::vector<u64> cap;
     u32 n_polys = 0;
+    explicit Commit(glp_ctx* c) : coeffs(c), lde(c), dig(c) {}
 };
 }  // namespace
 
-struct glp_plonk_circuit {
+struct glp_plonk_circuit {       // must be freed (glp_plonk_free) before its ctx is destroyed
     u32 log_n, W, rate_bits, cap_h;
     u64 shift;
     DBuf sigma_vals;            // [W][n] values on the trace domain (K6 input)
     DBuf ks, inv_xm1;
     std::vector<u64> h_ks;
     Commit pre;                 // constants + sigmas
+    explicit glp_plonk_circuit(glp_ctx* c) : sigma_vals(c), ks(c), inv_xm1(c), pre(c) {}
 };
 
 // values [n_polys][n] (device, consumed: turned into coefficients in place) -> Commit
@@ -50,7 +47,7 @@ static int commit_values(glp_ctx* c, u64* d_vals_owned, u32 n_polys, u32 log_n, 
     const u32 log_N = log_n + rb;
     const u64 N = 1ull << log_N;
     out.n_polys = n_polys;
-    out.coeffs.p = d_vals_owned;
+    out.coeffs.adopt(d_vals_owned);
     int rc = glp_ntt(c, out.coeffs.u(), log_n, n_polys, 1);
     if (rc) return rc;
     GLP_HIPCHK(c, out.lde.alloc((size_t)n_polys * N * 8));
@@ -71,7 +68,7 @@ extern "C" int glp_plonk_setup(glp_ctx* c, uint32_t log_n, uint32_t n_wires, con
         return GLP_E_INVALID;
     }
     if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set"); return GLP_E_STATE; }
-    std::unique_ptr<glp_plonk_circuit> ck(new glp_plonk_circuit());
+    std::unique_ptr<glp_plonk_circuit> ck(new glp_plonk_circuit(c));
     ck->log_n = log_n; ck->W = n_wires; ck->rate_bits = rate_bits; ck->cap_h = cap_height; ck->shift = 7;
     const u64 n = 1ull << log_n;
     const u32 log_N = log_n + rate_bits;
@@ -84,8 +81,8 @@ extern "C" int glp_plonk_setup(glp_ctx* c, uint32_t log_n, uint32_t n_wires, con
     GLP_HIPCHK(c, ck->sigma_vals.alloc((size_t)n_wires * n * 8));
     GLP_HIPCHK(c, hipMemcpyAsync(ck->sigma_vals.p, d_sigma_vals, (size_t)n_wires * n * 8, hipMemcpyDeviceToDevice, c->stream));
     // batch 0 = [q, c0, c1, sigma_0 .. sigma_{W-1}]
-    u64* pre_vals = nullptr;
-    GLP_HIPCHK(c, hipMalloc((void**)&pre_vals, (size_t)(3 + n_wires) * n * 8));
+    u64* pre_vals = (u64*)glp_pool_alloc(c, (size_t)(3 + n_wires) * n * 8);
+    if (!pre_vals) return GLP_E_NOMEM;
     GLP_HIPCHK(c, hipMemcpyAsync(pre_vals, d_const_vals, (size_t)3 * n * 8, hipMemcpyDeviceToDevice, c->stream));
     GLP_HIPCHK(c, hipMemcpyAsync(pre_vals + 3 * n, d_sigma_vals, (size_t)n_wires * n * 8, hipMemcpyDeviceToDevice, c->stream));
     int rc = commit_values(c, pre_vals, 3 + n_wires, log_n, rate_bits, cap_height, ck->pre);
@@ -131,10 +128,10 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
     c->stages.clear(); c->stage_name.clear();
     glp_stage_mark(c, "commit_wires(ifft+lde+merkle)");
     // ---- wires ----------------------------------------------------------------------------
-    Commit wires;
+    Commit wires(c);
     {
-        u64* wv = nullptr;
-        GLP_HIPCHK(c, hipMalloc((void**)&wv, (size_t)W * n * 8));
+        u64* wv = (u64*)glp_pool_alloc(c, (size_t)W * n * 8);
+        if (!wv) return GLP_E_NOMEM;
         GLP_HIPCHK(c, hipMemcpyAsync(wv, d_wire_vals, (size_t)W * n * 8, hipMemcpyDeviceToDevice, c->stream));
         int rc = commit_values(c, wv, W, log_n, rb, ck->cap_h, wires);
         if (rc) return rc;
@@ -149,13 +146,14 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
     const u64* wn_lo = nullptr; const u64* wn_hi = nullptr;
     int rc = glp_ntt_table(c, (int)log_n, 0, &wn_lo, &wn_hi);
     if (rc) return rc;
-    DBuf qv, rr, bprod;
+    DBuf qv(c), rr(c), bprod(c);
     u64* zs_vals = nullptr;
     GLP_HIPCHK(c, qv.alloc((size_t)GLP_PLONK_NCHAL * M * n * 8));
     GLP_HIPCHK(c, rr.alloc((size_t)GLP_PLONK_NCHAL * n * 8));
-    GLP_HIPCHK(c, hipMalloc((void**)&zs_vals, (size_t)GLP_PLONK_NCHAL * M * n * 8));
-    Commit zs;
-    zs.coeffs.p = zs_vals;          // owned from here on (freed on any early return)
+    zs_vals = (u64*)glp_pool_alloc(c, (size_t)GLP_PLONK_NCHAL * M * n * 8);
+    if (!zs_vals) return GLP_E_NOMEM;
+    Commit zs(c);
+    zs.coeffs.adopt(zs_vals);       // owned from here on (released on any early return)
     {
         GlpPermArgs pa;
         pa.wires = d_wire_vals; pa.sigmas = ck->sigma_vals.u(); pa.ks = ck->ks.u(); pa.log_n = log_n; pa.W = W;
@@ -172,7 +170,7 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
         hipLaunchKernelGGL(glp_scan_apply_kernel<0>, dim3(nb, GLP_PLONK_NCHAL), dim3(256), 0, c->stream, rr.u(), qv.u(), n, M, bprod.u(), zs_vals);
         GLP_HIPCHK(c, hipGetLastError());
     }
-    zs.coeffs.p = nullptr;
+    zs.coeffs.release();
     glp_stage_mark(c, "commit_zs");
     rc = commit_values(c, zs_vals, GLP_PLONK_NCHAL * M, log_n, rb, ck->cap_h, zs);
     if (rc) return rc;
@@ -184,7 +182,7 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
     const u32 n_con = 1 + 3 * M;
     std::vector<u64> apow((size_t)GLP_PLONK_NCHAL * n_con);
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) { u64 x = 1; for (u32 k = 0; k < n_con; k++) { apow[(size_t)t * n_con + k] = x; x = gl_mul(x, alpha[t]); } }
-    DBuf d_apow, quot_rev;
+    DBuf d_apow(c), quot_rev(c);
     GLP_HIPCHK(c, d_apow.alloc(apow.size() * 8));
     GLP_HIPCHK(c, hipMemcpyAsync(d_apow.p, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, c->stream));
     GLP_HIPCHK(c, quot_rev.alloc((size_t)GLP_PLONK_NCHAL * N * 8));
@@ -207,10 +205,10 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
         GLP_HIPCHK(c, hipGetLastError());
     }
     // evaluations (bit-reversed, coset) -> coefficients: un-bit-reverse, inverse NTT, unshift
-    u64* quot_nat = nullptr;
-    GLP_HIPCHK(c, hipMalloc((void**)&quot_nat, (size_t)GLP_PLONK_NCHAL * N * 8));
-    Commit quot;
-    quot.coeffs.p = quot_nat;
+    u64* quot_nat = (u64*)glp_pool_alloc(c, (size_t)GLP_PLONK_NCHAL * N * 8);
+    if (!quot_nat) return GLP_E_NOMEM;
+    Commit quot(c);
+    quot.coeffs.adopt(quot_nat);
     hipLaunchKernelGGL(glp_bitrev_permute_kernel<0>, dim3((unsigned)(((u64)GLP_PLONK_NCHAL * N + 255) / 256)), dim3(256), 0, c->stream,
                        quot_rev.u(), quot_nat, log_N, GLP_PLONK_NCHAL);
     GLP_HIPCHK(c, hipGetLastError());
@@ -224,7 +222,7 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
         const u64 s4096 = t;
         t = 1;
         for (size_t k = 0; k < hi.size(); k++) { hi[k] = t; t = gl_mul(t, s4096); }
-        DBuf dlo, dhi;
+        DBuf dlo(c), dhi(c);
         GLP_HIPCHK(c, dlo.alloc(lo.size() * 8));
         GLP_HIPCHK(c, dhi.alloc(hi.size() * 8));
         GLP_HIPCHK(c, hipMemcpyAsync(dlo.p, lo.data(), lo.size() * 8, hipMemcpyHostToDevice, c->stream));

@@ -51,6 +51,9 @@ int glp_free(glp_ctx* ctx, void* d_ptr);
 int glp_h2d(glp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);  /* synchronous */
 int glp_d2h(glp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);  /* synchronous */
 int glp_sync(glp_ctx* ctx);
+/* the prover drivers keep their temporaries in a ctx-owned pool (reused across proofs, no hipFree on
+ * the hot path); this returns every cached block to the driver (GLP_POOL_CAP_MB caps the cache) */
+int glp_trim_pool(glp_ctx* ctx);
 /* adopt an external hipStream_t (e.g. torch's current stream); NULL restores the ctx's own */
 int glp_set_stream(glp_ctx* ctx, void* hip_stream);
 /* HIP-event timer on the ctx's stream: start, enqueue work, stop -> elapsed milliseconds */
