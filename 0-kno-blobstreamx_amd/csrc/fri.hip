@@ -331,20 +331,37 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
         std::vector<u64> hc(2 * M);
         GLP_HIPCHK(c, hipMemcpyAsync(hc.data(), cur.p, hc.size() * 8, hipMemcpyDeviceToHost, c->stream));
         GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
-        const u64 w = gl_root_of_unity(log_len), winv = gl_inv(w), minv = gl_inv(M % GL_P), sinv = gl_inv(shift);
+        const u64 winv = gl_inv(gl_root_of_unity(log_len)), minv = gl_inv(M % GL_P), sinv = gl_inv(shift);
         std::vector<gl_ext2> nat(M);
         for (u64 i = 0; i < M; i++) {
             u64 r = 0;
             for (u32 bb = 0; bb < log_len; bb++) r |= ((i >> bb) & 1ull) << (log_len - 1 - bb);
             nat[r] = gl_ext2{hc[2 * i], hc[2 * i + 1]};
         }
+        // inverse DFT (host radix-2, O(M log M): nat[] is in natural order, bit-reverse then DIT with
+        // w^-1), scale by 1/M, then un-shift: co_j = c_j * shift^-j
         std::vector<gl_ext2> co(M);
-        for (u64 j = 0; j < M; j++) {                       // inverse DFT, then un-shift
-            const u64 wj = gl_pow(winv, j);
-            gl_ext2 acc{0, 0};
-            u64 t = 1;
-            for (u64 k = 0; k < M; k++) { acc = gl_ext_add(acc, gl_ext_scale(nat[k], t)); t = gl_mul(t, wj); }
-            co[j] = gl_ext_scale(acc, gl_mul(minv, gl_pow(sinv, j)));
+        for (u64 i = 0; i < M; i++) {
+            u64 r = 0;
+            for (u32 bb = 0; bb < log_len; bb++) r |= ((i >> bb) & 1ull) << (log_len - 1 - bb);
+            co[r] = nat[i];
+        }
+        for (u32 st = 1; st <= log_len; st++) {
+            const u64 half = 1ull << (st - 1), m2 = half << 1;
+            const u64 ws = gl_pow(winv, M >> st);
+            for (u64 k = 0; k < M; k += m2) {
+                u64 t = 1;
+                for (u64 j = 0; j < half; j++) {
+                    const gl_ext2 u = co[k + j], v = gl_ext_scale(co[k + j + half], t);
+                    co[k + j] = gl_ext_add(u, v);
+                    co[k + j + half] = gl_ext_sub(u, v);
+                    t = gl_mul(t, ws);
+                }
+            }
+        }
+        {
+            u64 sc = minv;
+            for (u64 j = 0; j < M; j++) { co[j] = gl_ext_scale(co[j], sc); sc = gl_mul(sc, sinv); }
         }
         for (u64 j = (1ull << final_bits); j < M; j++)
             if (co[j].a || co[j].b) { glp_set_err(c, "glp_fri_prove: final codeword is not of degree < 2^%u (inconsistent batches?)", final_bits); return GLP_E_INVALID; }
