@@ -408,7 +408,7 @@ def main():
         kern_ms = sum(pass_ms)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         out = {
-            "metric": "Goldilocks NTT GB/s @ 2^20-2^24", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
+            "metric": "Goldilocks NTT GB/s @ 2^20\u20132^24", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"forward NTT, n=2^{log_n}, batch={batch} per GPU, in place, natural order "
