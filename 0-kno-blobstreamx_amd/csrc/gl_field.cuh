@@ -44,9 +44,78 @@ GL_HD u64 gl_add(u64 a, u64 b) {
     const bool over = (s < a) | (s >= GL_P);     // true sum >= p
     return s + (over ? GL_EPS : 0ULL);            // - p  (mod 2^64)
 }
+// ---- gfx950 carry-chain forms ----------------------------------------------------------
+// The compiler turns `(a < b) ? d - eps : d` into 7 VALU (64-bit compare + two selects); with the
+// borrow kept in an SGPR lane mask it is 4 VALU + 1 SALU.  Measured issue costs are ~4.2 cycles
+// for every carry/64-bit/VOP3 op (profiles/r01_ubench_valu2.txt), so the instruction count is
+// the cost.  gfx940+ needs 2 wait states between a VALU writing an SGPR and a VALU reading it
+// (the compiler's hazard recogniser does not look inside inline asm): the s_nop's below.
+// s_andn2/s_or write SCC, which the compiler may hold live (s_add_u32/s_addc_u32 address
+// arithmetic): every block with a SALU op declares the "scc" clobber.
+// Host code and tests/emu use the portable forms (GLP_ASM_FIELD off).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GLP_EMU) && !defined(GLP_NO_ASM_FIELD)
+#define GLP_ASM_FIELD 1
+#else
+#define GLP_ASM_FIELD 0
+#endif
+
+GL_HD u64 gl_make64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+// a - b (+ p on borrow), valid for any u64 a and b <= p; canonical when a is
 GL_HD u64 gl_sub(u64 a, u64 b) {
+#if GLP_ASM_FIELD
+    u32 dl, dh;
+    u64 B, K;
+    asm("v_sub_co_u32 %0, %2, %4, %6\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32 %1, %2, %5, %7, %2\n\t"          // B = borrow of a - b
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %0, %3, 0, %0, %2\n\t"            // + p = (+1, -1 on the high word): lo += B, carry K
+        "s_andn2_b64 %2, %2, %3\n\t"
+        "v_subbrev_co_u32 %1, %3, 0, %1, %2"              // hi -= (B & ~K)
+        : "=&v"(dl), "=&v"(dh), "=&s"(B), "=&s"(K)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "scc");
+    return gl_make64(dl, dh);
+#else
     u64 d = a - b;
     return (a < b) ? d - GL_EPS : d;  // d + p (mod 2^64)
+#endif
+}
+
+// w * (2^32 - 1) + t  mod p for any u32 w and any u64 t: one v_mad_u64_u32 with its carry-out.
+// CANON: canonical result; otherwise a representative in [0, 2^64).
+template <bool CANON>
+GL_HD u64 gl_mad_eps(u32 w, u64 t) {
+#if GLP_ASM_FIELD
+    u64 r, C;
+    u32 m;
+    if constexpr (CANON) {
+        u64 G;
+        asm("v_mad_u64_u32 %0, %1, %4, -1, %5\n\t"
+            "v_cmp_le_u64 %2, %6, %0\n\t"
+            "s_or_b64 %1, %1, %2\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32 %3, 0, -1, %1"
+            : "=&v"(r), "=&s"(C), "=&s"(G), "=v"(m)
+            : "v"(w), "v"(t), "s"(GL_P)
+            : "scc");
+    } else {
+        asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %2, 0, -1, %1"
+            : "=&v"(r), "=&s"(C), "=v"(m)
+            : "v"(w), "v"(t));
+    }
+    // wrapped: r <= 2^64 - 2^33, so + eps neither overflows nor reaches p; else r - p < 2^32
+    return r + (u64)m;
+#else
+    const u64 t1 = ((u64)w << 32) - w;
+    u64 r;
+    const bool c = __builtin_add_overflow(t, t1, &r);
+    if (CANON) return r + ((c | (r >= GL_P)) ? GL_EPS : 0ULL);
+    return r + (c ? GL_EPS : 0ULL);
+#endif
 }
 GL_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 GL_HD u64 gl_canon(u64 a) { return a >= GL_P ? a - GL_P : a; }
@@ -55,58 +124,57 @@ GL_HD u64 gl_canon(u64 a) { return a >= GL_P ? a - GL_P : a; }
 GL_HD u64 gl_fold_carry(u64 r, bool carry) { return r + ((carry | (r >= GL_P)) ? GL_EPS : 0ULL); }
 
 // (hi*2^64 + lo) mod p, any hi, lo:  lo - hi_hi + hi_lo*(2^32 - 1)
-GL_HD u64 gl_reduce128(u64 hi, u64 lo) {
+template <bool CANON>
+GL_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
     const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+#if GLP_ASM_FIELD
+    // t0 = lo - h1 (+ p on borrow; the wrapped value is >= 2^64 - 2^32 so "- eps" cannot underflow)
+    u32 tl, th;
+    u64 B, K;
+    asm("v_sub_co_u32 %0, %2, %4, %6\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %1, %2, 0, %5, %2\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %0, %3, 0, %0, %2\n\t"
+        "s_andn2_b64 %2, %2, %3\n\t"
+        "v_subbrev_co_u32 %1, %3, 0, %1, %2"
+        : "=&v"(tl), "=&v"(th), "=&s"(B), "=&s"(K)
+        : "v"((u32)lo), "v"((u32)(lo >> 32)), "v"(h1)
+        : "scc");
+    return gl_mad_eps<CANON>(h0, gl_make64(tl, th));
+#else
     u64 t0;
     const bool bor = __builtin_sub_overflow(lo, (u64)h1, &t0);
     t0 = bor ? t0 + GL_P : t0;                    // -2^64 = +p - 2^64 ... (mod 2^64): t0 - eps
-    const u64 t1 = ((u64)h0 << 32) - h0;          // h0 * (2^32 - 1)  <= 2^64 - 2^33 + 1
-    u64 r;
-    const bool c = __builtin_add_overflow(t0, t1, &r);
-    return gl_fold_carry(r, c);                   // carry: r + eps < p (r < t1); else one conditional subtract
+    return gl_mad_eps<CANON>(h0, t0);
+#endif
 }
+GL_HD u64 gl_reduce128(u64 hi, u64 lo) { return gl_reduce128_t<true>(hi, lo); }
 
-GL_HD u64 gl_mul(u64 a, u64 b) {
-    // 64x64 -> 128 from four 32x32 products chained through v_mad_u64_u32 addends
+// 64x64 -> 128 from four 32x32 products chained through v_mad_u64_u32 addends
+template <bool CANON>
+GL_HD u64 gl_mul_t(u64 a, u64 b) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 p0 = (u64)a0 * b0;
     const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
     const u64 p2 = (u64)a1 * b0 + (u32)p1;
     const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
-    return gl_reduce128(p3, (p2 << 32) | (u32)p0);
+    return gl_reduce128_t<CANON>(p3, (p2 << 32) | (u32)p0);
 }
+GL_HD u64 gl_mul(u64 a, u64 b) { return gl_mul_t<true>(a, b); }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 
 // "nc" = not canonicalised: inputs may be ANY u64 representative, the result is a correct
 // representative in [0, 2^64) that may be >= p.  Saves the (r >= p) compare of every product in
 // long multiplication chains whose end result is canonicalised once (Poseidon S-boxes).
-GL_HD u64 gl_mul_nc(u64 a, u64 b) {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 p0 = (u64)a0 * b0;
-    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
-    const u64 p2 = (u64)a1 * b0 + (u32)p1;
-    const u64 hi = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32), lo = (p2 << 32) | (u32)p0;
-    const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
-    u64 t0;
-    const bool bor = __builtin_sub_overflow(lo, (u64)h1, &t0);
-    t0 = bor ? t0 + GL_P : t0;
-    const u64 t1 = ((u64)h0 << 32) - h0;
-    u64 r;
-    const bool c = __builtin_add_overflow(t0, t1, &r);
-    return r + (c ? GL_EPS : 0ULL);               // carry: r < t1 <= 2^64 - 2^33 + 1, no second overflow
-}
+GL_HD u64 gl_mul_nc(u64 a, u64 b) { return gl_mul_t<false>(a, b); }
 
 // ---- multiplication by powers of two (the twiddles of every radix <= 64 butterfly) ------
 // x * 2^T, 0 < T < 32:  (x << T) + (x >> (64-T)) * (2^32 - 1)
 template <int T>
 GL_HD u64 gl_shl_small(u64 x) {
     static_assert(T > 0 && T < 32, "");
-    const u64 lo = x << T;
-    const u32 w2 = (u32)(x >> (64 - T));
-    const u64 t1 = ((u64)w2 << 32) - w2;
-    u64 r;
-    const bool c = __builtin_add_overflow(lo, t1, &r);
-    return gl_fold_carry(r, c);
+    return gl_mad_eps<true>((u32)(x >> (64 - T)), x << T);
 }
 // x * 2^-K, 0 < K <= 32, branch-free and already canonical (Montgomery-style exact division):
 // m = -x mod 2^K makes x + m*p divisible by 2^K (p = 1 mod 2^32), and
