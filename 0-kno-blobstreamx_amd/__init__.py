@@ -23,7 +23,7 @@ NTT_INVERSE = 1
 NTT_BITREV = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libglprover.so")
+LIB_PATH = os.environ.get("GLP_LIB") or os.path.join(_HERE, "lib", "libglprover.so")   # GLP_LIB: A/B builds (tuning)
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _vp = ctypes.c_void_p

@@ -39,11 +39,6 @@ GL_HD void glp_static_for(F&& f) {
 // v_mad_u64_u32, v_cmp_*, v_cndmask, v_add_co/v_addc) in ~4.2.  Hence "+ (cond ? eps : 0)"
 // (one v_cndmask + one 64-bit add) rather than computing both candidates and selecting
 // (one more 64-bit add and a second v_cndmask).
-GL_HD u64 gl_add(u64 a, u64 b) {
-    const u64 s = a + b;
-    const bool over = (s < a) | (s >= GL_P);     // true sum >= p
-    return s + (over ? GL_EPS : 0ULL);            // - p  (mod 2^64)
-}
 // ---- gfx950 carry-chain forms ----------------------------------------------------------
 // The compiler turns `(a < b) ? d - eps : d` into 7 VALU (64-bit compare + two selects); with the
 // borrow kept in an SGPR lane mask it is 4 VALU + 1 SALU.  Measured issue costs are ~4.2 cycles
@@ -60,6 +55,14 @@ GL_HD u64 gl_add(u64 a, u64 b) {
 #endif
 
 GL_HD u64 gl_make64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+// canonical a + b.  (A 5-VALU lane-mask form of the fix-up measured the same as this select form on
+// the NTT passes, 1560 vs 1563 GB/s A/B in one run, so the portable form stays.)
+GL_HD u64 gl_add(u64 a, u64 b) {
+    const u64 s = a + b;
+    const bool over = (s < a) | (s >= GL_P);     // true sum >= p
+    return s + (over ? GL_EPS : 0ULL);            // - p  (mod 2^64)
+}
 
 // a - b (+ p on borrow), valid for any u64 a and b <= p; canonical when a is
 GL_HD u64 gl_sub(u64 a, u64 b) {
@@ -188,7 +191,7 @@ GL_HD u64 gl_shr_small(u64 x) {
     return a + (((u64)mm << 32) - mm);
 }
 // x * 2^32 = -x1 + (x0 + x1) * 2^32  ... as reduce128(hi = x >> 32, lo = x << 32)
-GL_HD u64 gl_shl32(u64 x) { return gl_reduce128(x >> 32, x << 32); }
+GL_HD u64 gl_shl32(u64 x) { return gl_mad_eps<true>((u32)(x >> 32), x << 32); }   // hi_hi = 0: no subtraction
 
 // |x * 2^S| up to sign, S in [0,192): returns v with  x * 2^S = (gl_pow2_neg(S) ? -v : v).
 // Every case is one or two of the primitives above; exponents 32 < e < 96 go through the

@@ -271,54 +271,69 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                     lds[base + ((u32)d << lsg) * ldA] = v;
                 });
             } else {
-                // inter-pass twiddle of a STRIP pass: X[k] *= w_N^{j' k}, j' = lo0 + col.  The 16
-                // outputs of this work-item are k = k0 + d*(R/r), so the factors form a geometric
-                // progression: two table look-ups (base, ratio) and a running product instead
-                // of 16 pairs of gathered loads.
-                u64 tw = 1, ratio = 1;
-                const u64* twf = nullptr;
-                if constexpr (MODE == GLP_STRIP) twf = a.tw_full;
-                if (MODE == GLP_STRIP && !twf) {
-                    const u32 log_N = LOG_R + a.log_m;
-                    const u64 jq = (u64)(lo0 + col);
-                    const u64 e0 = jq * glp_digit_reverse<LOG_R, LOG_E>(row0);      // < N <= 2^32
-                    const u64 e1 = jq << (LOG_R - q);                        // j' * R/r
-                    if (log_N <= 12) {
-                        tw = a.tw_lo[e0];
-                        ratio = a.tw_lo[e1];
-                    } else {
-                        tw = gl_mul(a.tw_lo[e0 & 4095u], a.tw_hi[e0 >> 12]);
-                        ratio = gl_mul(a.tw_lo[e1 & 4095u], a.tw_hi[e1 >> 12]);
+                // sigma == 1 in the last step: the 2^q outputs of this work-item are the natural indices
+                // k = k0 + d * (R/r), so every address below is a base plus a wave-uniform multiple of d.
+                const u32 k0 = glp_digit_reverse<LOG_R, LOG_E>(row0);
+                constexpr int KS = LOG_R - q;                               // log2 of the k stride
+                if constexpr (MODE == GLP_STRIP) {
+                    // inter-pass twiddle X[k] *= w_N^{j' k}, j' = lo0 + col: a geometric progression in d
+                    // (two table look-ups + a running product instead of 16 pairs of gathered loads)
+                    u64 tw = 1, ratio = 1;
+                    const u64* const twf = a.tw_full;
+                    if (!twf) {
+                        const u32 log_N = LOG_R + a.log_m;
+                        const u64 jq = (u64)(lo0 + col);
+                        const u64 e0 = jq * k0;                                  // < N <= 2^32
+                        const u64 e1 = jq << KS;                                 // j' * R/r
+                        if (log_N <= 12) {
+                            tw = a.tw_lo[e0];
+                            ratio = a.tw_lo[e1];
+                        } else {
+                            tw = gl_mul(a.tw_lo[e0 & 4095u], a.tw_hi[e0 >> 12]);
+                            ratio = gl_mul(a.tw_lo[e1 & 4095u], a.tw_hi[e1 >> 12]);
+                        }
                     }
-                }
-                glp_static_for<0, (int)r>([&](auto d_) {
-                    constexpr int d = decltype(d_)::value;
-                    u64 v = x[g * r + glp_bitrev_c(d, q)];
-                    const u32 pos = row0 + (u32)d;                  // sigma == 1 in the last step
-                    const u32 k = glp_digit_reverse<LOG_R, LOG_E>(pos);    // natural output index in [0,R)
-                    if constexpr (MODE == GLP_STRIP) {
+                    // natural order: row k; bit-reversed: row bitrev(k) = bitrev(k0) + bitrev_q(d)
+                    const u32 orow0 = a.rev ? glp_bitrev32(k0, LOG_R) : k0;
+                    const u64 p0 = dbase + ((u64)orow0 << a.log_m) + col;
+                    const u32 sh = a.rev ? a.log_m : a.log_m + KS;
+                    glp_static_for<0, (int)r>([&](auto d_) {
+                        constexpr int d = decltype(d_)::value;
+                        u64 v = x[g * r + glp_bitrev_c(d, q)];
                         if (twf) {
-                            v = gl_mul(v, twf[((u64)k << a.log_m) + lo0 + col]);
+                            v = gl_mul(v, twf[((u64)(k0 + ((u32)d << KS)) << a.log_m) + lo0 + col]);
                         } else {
                             v = gl_mul(v, tw);
                             if constexpr (d + 1 < (int)r) tw = gl_mul(tw, ratio);
                         }
-                        const u32 orow = a.rev ? glp_bitrev32(k, LOG_R) : k;
-                        a.dst[dbase + ((u64)orow << a.log_m) + col] = v;
-                    } else if constexpr (MODE == GLP_FINAL_T) {
-                        if (a.scale != 1) v = gl_mul(v, a.scale);
-                        const u64 grow = row_first + col;           // = poly*Q + kappa
-                        if (grow < total_rows) {
-                            const u64 poly = grow >> log_rows;
-                            const u64 kappa = grow & ((1ull << log_rows) - 1);
-                            a.dst[poly * a.dst_poly_stride + ((u64)k << log_rows) + kappa] = v;
-                        }
-                    } else {
-                        if (a.scale != 1) v = gl_mul(v, a.scale);
-                        const u32 kout = a.rev ? glp_bitrev32(k, LOG_R) : k;
-                        lds[col * (R + 1u) + kout] = v;             // layout B: [col][R+1]
+                        const u64 dm = a.rev ? (u64)glp_bitrev_c(d, q) : (u64)d;
+                        a.dst[p0 + (dm << sh)] = v;
+                    });
+                } else if constexpr (MODE == GLP_FINAL_T) {
+                    const u64 grow = row_first + col;                        // = poly*Q + kappa
+                    if (grow < total_rows) {
+                        const u64 poly = grow >> log_rows;
+                        const u64 kappa = grow & ((1ull << log_rows) - 1);
+                        const u64 p0 = poly * a.dst_poly_stride + ((u64)k0 << log_rows) + kappa;
+                        const u32 sh = KS + log_rows;
+                        glp_static_for<0, (int)r>([&](auto d_) {
+                            constexpr int d = decltype(d_)::value;
+                            u64 v = x[g * r + glp_bitrev_c(d, q)];
+                            if (a.scale != 1) v = gl_mul(v, a.scale);
+                            a.dst[p0 + ((u64)d << sh)] = v;
+                        });
                     }
-                });
+                } else {
+                    const u32 kb = col * (R + 1u) + (a.rev ? glp_bitrev32(k0, LOG_R) : k0);   // layout B: [col][R+1]
+                    const u32 sh = a.rev ? 0u : (u32)KS;
+                    glp_static_for<0, (int)r>([&](auto d_) {
+                        constexpr int d = decltype(d_)::value;
+                        u64 v = x[g * r + glp_bitrev_c(d, q)];
+                        if (a.scale != 1) v = gl_mul(v, a.scale);
+                        const u32 dm = a.rev ? (u32)glp_bitrev_c(d, q) : (u32)d;
+                        lds[kb + (dm << sh)] = v;
+                    });
+                }
             }
         });
         if constexpr (!last || MODE == GLP_FINAL_ROWS) __syncthreads();
