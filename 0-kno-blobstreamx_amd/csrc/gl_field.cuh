@@ -167,6 +167,32 @@ GL_HD u64 gl_mul_t(u64 a, u64 b) {
 GL_HD u64 gl_mul(u64 a, u64 b) { return gl_mul_t<true>(a, b); }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 
+// al + ah * 2^32 (mod p) for two 64-bit accumulators whose true value al + ah * 2^32 is < 2^64 * 2^32
+// and whose reduction  al + (ah mod 2^32) * 2^32 + (ah >> 32) * (2^32 - 1)  overflows 2^64 at most once
+// (Poseidon's small-integer dot products: al, ah < 2^57).  Result: a representative in [0, 2^64).
+GL_HD u64 gl_fold_small(u64 al, u64 ah) {
+#if GLP_ASM_FIELD
+    u32 lh, m;
+    u64 C1, C2, v;
+    asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(lh), "=s"(C1) : "v"((u32)(al >> 32)), "v"((u32)ah));
+    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
+        "s_or_b64 %1, %1, %5\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32 %2, 0, -1, %1"
+        : "=&v"(v), "=&s"(C2), "=v"(m)
+        : "v"((u32)(ah >> 32)), "v"(gl_make64((u32)al, lh)), "s"(C1)
+        : "scc");
+    return v + (u64)m;
+#else
+    const u64 l = al + (ah << 32);
+    const bool c1 = l < al;
+    const u64 t = (ah >> 32) * GL_EPS;
+    const u64 v = l + t;
+    const bool c2 = v < l;
+    return v + ((c1 | c2) ? GL_EPS : 0ULL);
+#endif
+}
+
 // "nc" = not canonicalised: inputs may be ANY u64 representative, the result is a correct
 // representative in [0, 2^64) that may be >= p.  Saves the (r >= p) compare of every product in
 // long multiplication chains whose end result is canonicalised once (Poseidon S-boxes).

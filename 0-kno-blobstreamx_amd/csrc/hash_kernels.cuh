@@ -54,8 +54,8 @@ GL_HD u64 glp_sbox7(u64 x) {
 // SMALL (every entry and their sum < 2^24): a row is two 64-bit accumulators of 32x32 products,
 //   al = sum lo_i c_i + rc_lo,  ah = sum hi_i c_i + rc_hi   (both < 2^57),
 // and  al + ah*2^32 = al + (ah mod 2^32)*2^32 + (ah >> 32)*(2^32 - 1)  (mod p)  overflows 2^64 at
-// most once, so one fused carry/canonical fix-up finishes the row (9 VALU instead of a generic
-// 128-bit reduction).
+// most once, so one fused carry fix-up (gl_fold_small) finishes the row instead of a generic
+// 128-bit reduction.
 template <bool SMALL>
 GL_HD void glp_mds_layer(u64 (&s)[12], const u64* __restrict__ circ, const u64* __restrict__ diag, const u64* __restrict__ rc_next) {
     u64 out[12];
@@ -75,12 +75,7 @@ GL_HD void glp_mds_layer(u64 (&s)[12], const u64* __restrict__ circ, const u64* 
                 al += (u64)lo[(i + r) % 12] * c[i];
                 ah += (u64)hi[(i + r) % 12] * c[i];
             });
-            const u64 l = al + (ah << 32);
-            const bool c1 = l < al;
-            const u64 t = (ah >> 32) * GL_EPS;
-            const u64 v = l + t;
-            const bool c2 = v < l;
-            out[r] = v + ((c1 | c2) ? GL_EPS : 0ULL);   // representative in [0, 2^64), canonicalised at the end
+            out[r] = gl_fold_small(al, ah);             // representative in [0, 2^64), canonicalised at the end
         });
     } else {
         glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = gl_canon(s[i]); });   // S-box outputs are not canonical
@@ -108,12 +103,7 @@ GL_HD u64 glp_dot_small(const u32 (&lo)[N], const u32 (&hi)[N], const u32* __res
         al += (u64)lo[i] * coef[i];
         ah += (u64)hi[i] * coef[i];
     });
-    const u64 l = al + (ah << 32);
-    const bool c1 = l < al;
-    const u64 t = (ah >> 32) * GL_EPS;
-    const u64 v = l + t;
-    const bool c2 = v < l;
-    return v + ((c1 | c2) ? GL_EPS : 0ULL);        // representative in [0, 2^64), not canonicalised
+    return gl_fold_small(al, ah);                   // representative in [0, 2^64), not canonicalised
 }
 
 // Three consecutive partial rounds at once.  Only lane 0 is non-linear, so the state before
