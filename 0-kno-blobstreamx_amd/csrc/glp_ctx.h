@@ -4,6 +4,7 @@
 #include <chrono>
 #include <map>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 #include "../../include/glprover.h"
@@ -25,6 +26,8 @@ struct glp_ctx {
     std::map<int, glp_table> tables;     // key = log_N*2 + inv
     std::map<int, u64*> full_tables;     // key = (log_N*64 + log_m)*2 + inv: per-element inter-pass twiddles
     std::map<uint32_t, std::string> plan_override;
+    // input-scale tables of the coset LDE, key = (shift, log_n, rate_bits, log_r, log_m) -> (row, col) on the device
+    std::map<std::tuple<u64, int, int, int, int>, std::pair<u64*, u64*>> coset_tables;
     u64* scratch = nullptr;
     size_t scratch_bytes = 0;
     size_t scratch_cap = 0;              // upper bound for NTT scratch; larger batches are chunked

@@ -195,6 +195,29 @@ struct HipBackend {
         c->full_tables[key] = d;
         return d;
     }
+    int coset_tables(int log_n, int rb, u64 shift, int log_r, int log_m, const u64** row, const u64** col) {
+        const auto key = std::make_tuple(shift, log_n, rb, log_r, log_m);
+        auto it = c->coset_tables.find(key);
+        if (it == c->coset_tables.end()) {
+            const size_t nr = (size_t)1 << (rb + log_r), nc = col ? ((size_t)1 << (rb + log_m)) : 0;
+            std::vector<u64> hr(nr), hc(nc ? nc : 1);
+            glp_fill_coset_tables(log_n, rb, shift, log_r, log_m, hr.data(), nc ? hc.data() : nullptr);
+            u64 *dr = nullptr, *dc = nullptr;
+            if (hipMalloc((void**)&dr, nr * 8) != hipSuccess) { glp_set_err(c, "coset table alloc"); return rc = GLP_E_NOMEM; }
+            if (nc && hipMalloc((void**)&dc, nc * 8) != hipSuccess) { hipFree(dr); glp_set_err(c, "coset table alloc"); return rc = GLP_E_NOMEM; }
+            // synchronous copies: the host vectors die at the end of this scope
+            if (hipMemcpy(dr, hr.data(), nr * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                (nc && hipMemcpy(dc, hc.data(), nc * 8, hipMemcpyHostToDevice) != hipSuccess)) {
+                hipFree(dr); if (dc) hipFree(dc);
+                glp_set_err(c, "coset table upload");
+                return rc = GLP_E_HIP;
+            }
+            it = c->coset_tables.emplace(key, std::make_pair(dr, dc)).first;
+        }
+        *row = it->second.first;
+        if (col) *col = it->second.second;
+        return GLP_OK;
+    }
     void mark(int idx) {
         if (c->profiling && idx < 2 * GLP_MAX_PASSES) hipEventRecord(c->pass_ev[idx], c->stream);
     }
@@ -263,6 +286,7 @@ extern "C" void glp_destroy(glp_ctx* c) {
     hipStreamSynchronize(c->stream);
     for (auto& kv : c->tables) { if (kv.second.lo) hipFree(kv.second.lo); if (kv.second.hi) hipFree(kv.second.hi); }
     for (auto& kv : c->full_tables) if (kv.second) hipFree(kv.second);
+    for (auto& kv : c->coset_tables) { if (kv.second.first) hipFree(kv.second.first); if (kv.second.second) hipFree(kv.second.second); }
     if (c->shift_lo) hipFree(c->shift_lo);
     if (c->shift_hi) hipFree(c->shift_hi);
     if (c->scratch) hipFree(c->scratch);
@@ -464,6 +488,27 @@ extern "C" int glp_lde_coset(glp_ctx* c, const uint64_t* coeffs, uint64_t* out, 
     if (batch == 0) return GLP_OK;
     const u32 log_N = log_n + rate_bits;
     const u64 n = 1ull << log_n;
+    if ((flags & GLP_NTT_BITREV) && rate_bits > 0 && log_n >= GLP_MIN_LOG_R && ((u64)batch << rate_bits) <= 0x7fffffffull &&
+        !getenv("GLP_LDE_PADDED")) {
+        // Bit-reversed output (what the prover commits to): 2^rate_bits size-n transforms per polynomial, one
+        // per coset, each landing in its contiguous block of the output row — no zero padding, no size-N
+        // passes: 2 passes over 8n points instead of pad + 3 passes (n = 2^20, rate 8).
+        GlpPlan pl;
+        const u32 vbatch = batch << rate_bits;
+        if (glp_make_plan((int)log_n, 1, 0, plan_override_for(c, log_n), &pl, vbatch) != 0 || pl.needs_scratch) {
+            glp_set_err(c, "glp_lde_coset: no plan for log_n=%u", log_n);
+            return GLP_E_UNSUPPORTED;
+        }
+        HipBackend be{c};
+        GlpNttCall call{coeffs, out, nullptr, n, n << rate_bits, vbatch, (int)log_n, 0, 1};
+        call.coset_log = rate_bits;
+        call.coset_shift = shift;
+        int rc = glp_exec_ntt(be, &pl, call);
+        if (rc != GLP_OK) { if (rc > -10 && c->err[0] == 0) glp_set_err(c, "glp_lde_coset: exec rc=%d", rc); return rc < -6 ? GLP_E_INVALID : rc; }
+        c->last_npass = be.npass;
+        return GLP_OK;
+    }
+    // natural-order output (and tiny sizes): zero-pad + scale, then one size-N transform
     // shift^j tables (two-level), cached for the last (shift, log_n)
     if (c->shift_val != shift || c->shift_log_n != (int)log_n) {
         const size_t nlo = n < 4096 ? n : 4096, nhi = n > 4096 ? (n >> 12) : 0;

@@ -7,6 +7,7 @@
 //   const u64* table_hi(int log_N, int inv);   // nullptr when log_N <= 12
 //   const u64* table_full(int log_N, int log_m, int inv);   // per-element inter-pass twiddles or nullptr
 //   int launch_pass(const GlpPass&, int inv, unsigned long long grid, unsigned block, size_t lds, const GlpNttPassArgs&);
+//   int coset_tables(int log_n, int rb, u64 shift, int log_r, int log_m, const u64** row, const u64** col);   // glp_fill_coset_tables
 //   int launch_small(const u64* src, u64* dst, u64 ss, u64 ds, u32 log_n, u32 batch, const u64* tw, u64 scale, u32 rev);
 #pragma once
 #include "ntt_kernels.cuh"
@@ -22,6 +23,10 @@ struct GlpNttCall {
     int log_n;
     int inverse;
     int rev;               // bit-reversed output order
+    // coset LDE (see GlpNttPassArgs::coset_log): batch counts virtual polynomials (real << coset_log),
+    // src rows hold n coefficients, dst rows n << coset_log values; requires rev
+    u32 coset_log = 0;
+    u64 coset_shift = 0;
 };
 
 template <class Backend>
@@ -29,6 +34,7 @@ int glp_exec_ntt(Backend& be, const GlpPlan* pl, const GlpNttCall& c) {
     const u64 n = 1ull << c.log_n;
     const u64 scale = c.inverse ? gl_inv(n % GL_P) : 1ull;
     if (c.batch == 0) return 0;
+    if (c.coset_log && (!c.rev || c.inverse || c.log_n < GLP_MIN_LOG_R || pl->needs_scratch)) return -5;
     if (c.log_n < GLP_MIN_LOG_R) {
         return be.launch_small(c.src, c.dst, c.src_poly_stride, c.dst_poly_stride, (u32)c.log_n, c.batch,
                                be.table_lo(c.log_n, c.inverse), scale, (u32)c.rev);
@@ -61,7 +67,7 @@ int glp_exec_ntt(Backend& be, const GlpPlan* pl, const GlpNttCall& c) {
             a.tw_hi = be.table_hi(log_N, c.inverse);
             // batched transforms of moderate size: one table multiply per element instead of the
             // running product (the table tile is shared by all polynomials through L2)
-            if (c.batch >= GLP_FULL_TW_MIN_BATCH && log_N <= GLP_FULL_TW_MAX_LOG_N) a.tw_full = be.table_full(log_N, ps.log_m, c.inverse);
+            if (!c.coset_log && c.batch >= GLP_FULL_TW_MIN_BATCH && log_N <= GLP_FULL_TW_MAX_LOG_N) a.tw_full = be.table_full(log_N, ps.log_m, c.inverse);
         }
         const int last = (i == pl->npass - 1);
         a.scale = last ? scale : 1ull;
@@ -74,6 +80,16 @@ int glp_exec_ntt(Backend& be, const GlpPlan* pl, const GlpNttCall& c) {
         if (ps.mode == GLP_FINAL_T) {
             a.nprev = (u32)i;
             for (int j = 0; j < i && j < 3; j++) a.log_rprev[j] = (u32)pl->p[j].log_r;
+        }
+        if (c.coset_log) {
+            a.coset_log = c.coset_log;
+            a.src_coset = (ps.in_buf != GLP_BUF_SRC) ? 1u : 0u;
+            if (i == 0) {
+                const int lm = (ps.mode == GLP_STRIP) ? ps.log_m : 0;
+                if (ps.log_r + lm != c.log_n) return -5;
+                int rc = be.coset_tables(c.log_n, (int)c.coset_log, c.coset_shift, ps.log_r, lm, &a.in_row, lm ? &a.in_col : nullptr);
+                if (rc) return rc;
+            }
         }
         unsigned long long grid = glp_pass_grid(&ps, c.log_n, c.batch);
         if (grid == 0 || grid > 0x7fffffffull) return -4;

@@ -80,6 +80,15 @@ struct GlpNttPassArgs {
     u32 xcd_group_log;     // STRIP with C*8 < 128 B: log2 of strips sharing one 128-B line (0 = no remap)
     const u64* tw_full;    // STRIP, optional: per-element inter-pass twiddles w_N^{j'k} at [k*m + j'] (batched sizes)
     u32 poly_minor;        // STRIP: consecutive workgroups walk the polynomials of one tile position first
+    // Low-degree extension by cosets (bit-reversed output): `batch` counts VIRTUAL polynomials
+    // v = (p << coset_log) | k — source polynomial p evaluated on the coset shift * w_N^k * <w_n> by a
+    // size-n transform of c_j * s_k^j.  Bit reversal of the N-point index puts that coset in the
+    // contiguous block bitrev(k) of destination row p, so nothing is zero-padded and no pass touches
+    // more than n points per (p, k).
+    u32 coset_log;         // log2 of the blow-up (0 = plain transform)
+    u32 src_coset;         // src already has the destination's coset-blocked layout (every pass but the first)
+    const u64* in_row;     // first pass: s_k^(row * m) at [(k << LOG_R) | row], multiplied into the loaded element
+    const u64* in_col;     // first pass when STRIP: s_k^c at [(k << log_m) | c], folded into the inter-pass twiddle
 };
 
 // LOG_E = log2 of the elements held per work-item (4: radix <= 16 steps, 5: radix <= 32 steps)
@@ -149,10 +158,18 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
         }
     }
 
+    // element offset of (virtual) polynomial v in a buffer of row stride `stride`
+    auto poly_off = [&](u64 v, u64 stride, bool blocked) -> u64 {
+        if (!a.coset_log) return v * stride;
+        const u32 kc = (u32)v & ((1u << a.coset_log) - 1u);
+        return (v >> a.coset_log) * stride + (blocked ? ((u64)glp_bitrev32(kc, a.coset_log) << a.log_n) : 0ull);
+    };
+    const u32 coset_mask = (1u << a.coset_log) - 1u;
+
     // ---- tile geometry -------------------------------------------------------------
     // STRIP: tile -> (poly, hi, lo0); element (row, col) at  hi*R*m + row*m + lo0 + col
     u64 sbase = 0, dbase = 0;
-    u32 lo0 = 0;
+    u32 lo0 = 0, kcos = 0;                   // STRIP: coset of this tile's (virtual) polynomial
     // FINAL_*: tile -> first of C global rows
     u64 row_first = 0;
     const u32 log_rows = a.log_n - LOG_R;    // rows per polynomial (FINAL modes)
@@ -176,8 +193,9 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
         const u32 hi = t >> log_mc;
         lo0 = (t & ((1u << log_mc) - 1u)) << log_c;
         const u64 off = ((u64)hi << (LOG_R + a.log_m)) + lo0;
-        sbase = poly * a.src_poly_stride + off;
-        dbase = poly * a.dst_poly_stride + off;
+        sbase = poly_off(poly, a.src_poly_stride, a.src_coset != 0) + off;
+        dbase = poly_off(poly, a.dst_poly_stride, true) + off;
+        kcos = (u32)poly & coset_mask;
     } else {
         row_first = tile << log_c;
     }
@@ -215,7 +233,9 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                     const u64 p = sbase + col;
                     glp_static_for<0, (int)r>([&](auto d_) {
                         constexpr int d = decltype(d_)::value;
-                        x[g * r + d] = a.src[p + ((u64)(row0 + ((u32)d << lsg)) << a.log_m)];
+                        u64 v = a.src[p + ((u64)(row0 + ((u32)d << lsg)) << a.log_m)];
+                        if (a.in_row) v = gl_mul(v, a.in_row[(kcos << LOG_R) + row0 + ((u32)d << lsg)]);
+                        x[g * r + d] = v;
                     });
                 } else {
                     u64 grow = row_first + col;      // global row handled by this column
@@ -233,10 +253,13 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                         }
                         rr = rho;
                     }
-                    const u64 p = poly * a.src_poly_stride + ((u64)rr << LOG_R) + row0;
+                    const u64 p = poly_off(poly, a.src_poly_stride, a.src_coset != 0) + ((u64)rr << LOG_R) + row0;
+                    const u32 kc = (u32)poly & coset_mask;
                     glp_static_for<0, (int)r>([&](auto d_) {
                         constexpr int d = decltype(d_)::value;
-                        x[g * r + d] = active ? a.src[p + ((u32)d << lsg)] : 0ull;
+                        u64 v = active ? a.src[p + ((u32)d << lsg)] : 0ull;
+                        if (a.in_row) v = gl_mul(v, a.in_row[(kc << LOG_R) + row0 + ((u32)d << lsg)]);   // single-pass sizes: m = 1
+                        x[g * r + d] = v;
                     });
                 }
             } else {
@@ -292,6 +315,8 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                             tw = gl_mul(a.tw_lo[e0 & 4095u], a.tw_hi[e0 >> 12]);
                             ratio = gl_mul(a.tw_lo[e1 & 4095u], a.tw_hi[e1 >> 12]);
                         }
+                        // the column's share s_k^(lo0 + col) of the input scale commutes with the row transform
+                        if (a.in_col) tw = gl_mul(tw, a.in_col[((u64)kcos << a.log_m) + lo0 + col]);
                     }
                     // natural order: row k; bit-reversed: row bitrev(k) = bitrev(k0) + bitrev_q(d)
                     const u32 orow0 = a.rev ? glp_bitrev32(k0, LOG_R) : k0;
@@ -314,7 +339,7 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                     if (grow < total_rows) {
                         const u64 poly = grow >> log_rows;
                         const u64 kappa = grow & ((1ull << log_rows) - 1);
-                        const u64 p0 = poly * a.dst_poly_stride + ((u64)k0 << log_rows) + kappa;
+                        const u64 p0 = poly_off(poly, a.dst_poly_stride, true) + ((u64)k0 << log_rows) + kappa;
                         const u32 sh = KS + log_rows;
                         glp_static_for<0, (int)r>([&](auto d_) {
                             constexpr int d = decltype(d_)::value;
@@ -348,7 +373,7 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
             if (grow < total_rows) {
                 const u64 poly = grow >> log_rows;
                 const u64 rr = grow & ((1ull << log_rows) - 1);
-                a.dst[poly * a.dst_poly_stride + (rr << LOG_R) + kk] = lds[col * (R + 1u) + kk];
+                a.dst[poly_off(poly, a.dst_poly_stride, true) + (rr << LOG_R) + kk] = lds[col * (R + 1u) + kk];
             }
         }
     }

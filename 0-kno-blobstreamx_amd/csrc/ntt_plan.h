@@ -180,3 +180,21 @@ static inline void glp_fill_table(int log_N, int inv, u64* lo, u64* hi) {
         for (size_t i = 0; i < nhi; i++) { hi[i] = t; t = gl_mul(t, wh); }
     }
 }
+
+// Input-scale tables of a coset LDE (GlpNttPassArgs::in_row / in_col).  Coset k of the 2^rb evaluates on
+// s_k * <w_n>, s_k = shift * w_N^k (N = n << rb).  First pass with tile size R = 2^log_r on the axis of
+// stride m = 2^log_m (m = n / R; 1 for single-pass sizes):
+//   row[(k << log_r) | r] = s_k^(r * m),   col[(k << log_m) | c] = s_k^c   (col may be null when m = 1)
+static inline void glp_fill_coset_tables(int log_n, int rb, u64 shift, int log_r, int log_m, u64* row, u64* col) {
+    const u64 wN = gl_root_of_unity((unsigned)(log_n + rb));
+    u64 s = shift;
+    for (u64 k = 0; k < (1ull << rb); k++, s = gl_mul(s, wN)) {
+        const u64 sm = gl_pow(s, 1ull << log_m);
+        u64 t = 1;
+        for (u64 r = 0; r < (1ull << log_r); r++) { row[(k << log_r) | r] = t; t = gl_mul(t, sm); }
+        if (col) {
+            t = 1;
+            for (u64 c = 0; c < (1ull << log_m); c++) { col[(k << log_m) | c] = t; t = gl_mul(t, s); }
+        }
+    }
+}

@@ -101,6 +101,7 @@ def emu():
     lib = ctypes.CDLL(os.path.join(d, "libglp_emu_asan.so" if asan else "libglp_emu.so"))
     lib.emu_ntt.argtypes = [u64p, u64p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint, ctypes.c_int,
                             ctypes.c_int, ctypes.c_char_p]
+    lib.emu_lde_coset_bitrev.argtypes = [u64p, u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64, ctypes.c_char_p]
     for name in ("emu_gl_add", "emu_gl_sub", "emu_gl_mul", "emu_gl_reduce128"):
         f = getattr(lib, name)
         f.restype = ctypes.c_uint64

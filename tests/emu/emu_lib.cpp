@@ -30,6 +30,16 @@ struct EmuBackend {
         }
         return full[key].data();
     }
+    std::map<int, std::vector<u64>> cos_row, cos_col;
+    int coset_tables(int log_n, int rb, u64 shift, int log_r, int log_m, const u64** row, const u64** col) {
+        const int key = (int)cos_row.size();
+        cos_row[key].resize((size_t)1 << (rb + log_r));
+        if (col) cos_col[key].resize((size_t)1 << (rb + log_m));
+        glp_fill_coset_tables(log_n, rb, shift, log_r, log_m, cos_row[key].data(), col ? cos_col[key].data() : nullptr);
+        *row = cos_row[key].data();
+        if (col) *col = cos_col[key].data();
+        return 0;
+    }
     void ensure(int log_N, int inv) {
         int key = log_N * 2 + inv;
         if (lo.count(key)) return;
@@ -90,6 +100,18 @@ extern "C" int emu_ntt(const u64* src, u64* dst, u64 src_stride, u64 dst_stride,
     std::vector<u64> scratch;
     if (log_n >= GLP_MIN_LOG_R && pl.needs_scratch) scratch.resize((size_t)batch << log_n);
     GlpNttCall c{src, dst, scratch.empty() ? nullptr : scratch.data(), src_stride, dst_stride, batch, log_n, inverse, rev};
+    return glp_exec_ntt(be, &pl, c);
+}
+
+// coset LDE with bit-reversed output: coeffs [batch][n] -> out [batch][n << rb]
+extern "C" int emu_lde_coset_bitrev(const u64* coeffs, u64* out, int log_n, int rb, unsigned batch, u64 shift, const char* plan_override) {
+    EmuBackend be;
+    GlpPlan pl;
+    int rc = glp_make_plan(log_n, 1, 0, plan_override, &pl, (unsigned long long)batch << rb);
+    if (rc) return rc;
+    GlpNttCall c{coeffs, out, nullptr, 1ull << log_n, 1ull << (log_n + rb), batch << rb, log_n, 0, 1};
+    c.coset_log = (u32)rb;
+    c.coset_shift = shift;
     return glp_exec_ntt(be, &pl, c);
 }
 

@@ -73,6 +73,33 @@ def test_emulated_ntt_vs_oracle(emu, oracle, log_n, batch, inv, rev, plan, in_pl
         assert np.array_equal(src, x), "out-of-place transform must not modify its source"
 
 
+LDE_CASES = [
+    # log_n, rate_bits, batch, plan (of the size-n transforms)
+    (6, 1, 3, None), (7, 3, 2, None), (10, 3, 3, None), (12, 2, 1, None), (13, 3, 2, None), (14, 1, 3, None),
+    (16, 3, 1, "8:4,8:4"), (16, 2, 2, "10:3,6:4"), (18, 1, 1, "6:4,6:4,6:4"), (15, 4, 1, None),
+]
+
+
+@pytest.mark.parametrize("log_n,rb,batch,plan", LDE_CASES)
+def test_emulated_coset_lde_bitrev_vs_oracle(emu, oracle, log_n, rb, batch, plan):
+    """LDE by cosets (2^rb size-n transforms per polynomial, input scale fused into the first pass,
+    each coset written to its block of the bit-reversed output) == padded size-N transform + bit reversal"""
+    rng = np.random.default_rng(4242 + log_n * 5 + rb)
+    n, N = 1 << log_n, 1 << (log_n + rb)
+    coeffs = rand_field(rng, (batch, n))
+    coeffs[0, :] = P - 1
+    shift = 7 if rb != 2 else int(rng.integers(2, 2**63))
+    ref = np.zeros((batch, N), dtype=np.uint64)
+    oracle.orc_lde_coset(ptr(coeffs), ptr(ref), log_n, rb, batch, shift)
+    oracle.orc_bitrev_rows(ptr(ref), log_n + rb, batch)
+    out = np.full((batch, N), 0xABCD, dtype=np.uint64)
+    src = coeffs.copy()
+    rc = emu.emu_lde_coset_bitrev(ptr(src), ptr(out), log_n, rb, batch, shift, plan.encode() if plan else None)
+    assert rc == 0
+    assert np.array_equal(out, ref)
+    assert np.array_equal(src, coeffs)
+
+
 def test_emulated_ntt_strided_batch(emu, oracle):
     """polynomials embedded in wider rows (stride > n) on both sides"""
     rng = np.random.default_rng(5)

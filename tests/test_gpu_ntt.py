@@ -116,6 +116,33 @@ def test_lde_vs_oracle(prover, oracle):
         assert np.array_equal(prover.lde(c, rate_bits, bitrev=True), wrev)
 
 
+@pytest.mark.parametrize("log_n,rate_bits,batch,shift,plan", [(6, 1, 5, 7, None), (12, 3, 3, 7, None), (16, 3, 2, 7, None),
+                                                              (16, 2, 3, 0x123456789ABCDEF, "10:3,6:4"), (18, 2, 1, 7, "6:4,6:4,6:4"),
+                                                              (20, 3, 1, 7, None), (17, 4, 2, 49, None)])
+def test_coset_lde_bitrev_by_cosets(prover, oracle, log_n, rate_bits, batch, shift, plan):
+    """bit-reversed LDE = 2^rate_bits size-n transforms per polynomial with the coset scale fused into the
+    first pass; must equal the padded size-N transform of the oracle, bit-reversed — and the product's own
+    padded path (GLP_LDE_PADDED)"""
+    rng = np.random.default_rng(31 * log_n + rate_bits)
+    c = rand_field(rng, (batch, 1 << log_n))
+    c[0, :] = P - 1
+    want = np.zeros((batch, 1 << (log_n + rate_bits)), dtype=np.uint64)
+    oracle.orc_lde_coset(ptr(c), ptr(want), log_n, rate_bits, batch, shift)
+    oracle.orc_bitrev_rows(ptr(want), log_n + rate_bits, batch)
+    if plan:
+        prover.set_plan(log_n, plan)
+    try:
+        assert np.array_equal(prover.lde(c, rate_bits, shift=shift, bitrev=True), want)
+    finally:
+        if plan:
+            prover.set_plan(log_n, None)
+    os.environ["GLP_LDE_PADDED"] = "1"
+    try:
+        assert np.array_equal(prover.lde(c, rate_bits, shift=shift, bitrev=True), want)
+    finally:
+        del os.environ["GLP_LDE_PADDED"]
+
+
 def test_transpose(prover):
     rng = np.random.default_rng(12)
     for rows, cols in ((1, 1), (3, 5), (32, 32), (33, 65), (135, 1024), (1000, 7)):
