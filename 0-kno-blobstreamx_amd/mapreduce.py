@@ -55,15 +55,15 @@ def allgather_leaf_proofs(local_blobs, n_leaves, padded_len, device=None):
         dist.all_gather_into_tensor(out, buf)
     else:
         out = buf
-    out = out.cpu()
+    rows = out.cpu().numpy()                      # one d2h copy; slicing below is memcpy, not per-byte Python
     proofs = [None] * n_leaves
-    for row in out:
-        idx, ln = HEADER.unpack(bytes(row[: HEADER.size].tolist()))
+    for row in rows:
+        idx, ln = HEADER.unpack(row[: HEADER.size].tobytes())
         if idx == 2**64 - 1:
             continue
-        if idx >= n_leaves or proofs[idx] is not None:
+        if idx >= n_leaves or proofs[idx] is not None or ln > rec - HEADER.size:
             raise ValueError(f"bad or duplicate leaf index {idx}")
-        proofs[idx] = bytes(row[HEADER.size: HEADER.size + ln].tolist())
+        proofs[idx] = row[HEADER.size: HEADER.size + ln].tobytes()
     missing = [i for i, p in enumerate(proofs) if p is None]
     if missing:
         raise ValueError(f"leaf proofs missing after all-gather: {missing[:8]}")
