@@ -224,7 +224,8 @@ class Prover:
         self._chk(self.lib.glp_timer_stop(self.ctx, ctypes.byref(ms)), "glp_timer_stop")
         return ms.value
 
-    FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "mul_pow2": 3, "inv": 4}
+    FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "mul_pow2": 3, "inv": 4, "reduce128": 5, "reduce128_lazy": 6, "mul_any": 7,
+                 "fold_small": 8, "mad_eps_lazy": 9, "mad_eps": 10}
 
     def field_op(self, op, a, b=None):
         """element-wise Goldilocks arithmetic on the GPU (the kernels' own device functions)"""

@@ -113,6 +113,13 @@ __global__ void __launch_bounds__(256) glp_field_op_kernel(int op, const u64* __
                 break;
             }
             case 4: r = x ? gl_inv(x) : 0; break;
+            // the reduction primitives under the products, with ARBITRARY u64 operands (parity tests only)
+            case 5: r = gl_reduce128(x, y); break;                       // (x * 2^64 + y) mod p
+            case 6: r = gl_canon(gl_reduce128_t<false>(x, y)); break;    // same through the non-canonical form
+            case 7: r = gl_canon(gl_mul_nc(x, y)); break;                // product of any two u64 representatives
+            case 8: r = gl_canon(gl_fold_small(x >> 7, y >> 7)); break;  // (x>>7) + (y>>7) * 2^32 mod p, both < 2^57
+            case 9: r = gl_canon(gl_mad_eps<false>((u32)y, x)); break;   // x + (y mod 2^32) * (2^32 - 1)
+            case 10: r = gl_mad_eps<true>((u32)y, x); break;
         }
         out[i] = r;
     }
@@ -540,7 +547,7 @@ extern "C" int glp_lde_coset(glp_ctx* c, const uint64_t* coeffs, uint64_t* out, 
 
 extern "C" int glp_field_op(glp_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n) {
     if (!c) return GLP_E_INVALID;
-    if (op < 0 || op > 4 || ((!a || !out || (!b && op < 4)) && n)) { glp_set_err(c, "glp_field_op: bad argument"); return GLP_E_INVALID; }
+    if (op < 0 || op > 10 || ((!a || !out || (!b && op != 4)) && n)) { glp_set_err(c, "glp_field_op: bad argument"); return GLP_E_INVALID; }
     if (n == 0) return GLP_OK;
     u64 blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;

@@ -299,7 +299,10 @@ def mapreduce_bench(leaves_per_rank=16, log_n=16, W=80):
     consts, sigmas, wires = synthetic_circuit(pr, log_n, W)
     ck = pkg.PlonkCircuit(pr, consts, sigmas)
     dw = pr.to_device(wires)
-    ck.prove_(dw, 28, 16)                                   # warm-up
+    # warm-up: one leaf per rank through the whole map + gather path (first-use costs of the proof
+    # pool, torch's host ops and the RCCL communicator are not part of a steady-state MapReduce)
+    mr.map_prove_gather(lambda i: ck.prove_(dw, 28, 16), world, padded_len=1 << 18,
+                        device=torch.device("cuda", local_rank) if world > 1 else None)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -63,6 +63,9 @@ int glp_timer_stop(glp_ctx* ctx, float* ms);
 /* ---- field arithmetic (upstream name recalled: GoldilocksField) ------
  * element-wise on device arrays of n canonical elements: out[i] = a[i] (op) b[i].
  * op: 0 add, 1 sub, 2 mul, 3 a[i] * 2^(b[i] mod 192), 4 inverse of a[i] (0 -> 0).
+ * ops 5..10 take ARBITRARY 64-bit words and expose the reduction primitives under the products
+ * (results canonical): 5 (a*2^64 + b) mod p, 6 the same through the lazy form, 7 a*b for any
+ * representatives, 8 (a>>7) + (b>>7)*2^32, 9/10 a + (b mod 2^32)*(2^32-1) lazy/canonical.
  * The prover never calls this; it exposes the exact device arithmetic of the kernels to
  * parity tests and to hosts that need a few field operations on resident data. */
 int glp_field_op(glp_ctx* ctx, int op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n);
