@@ -274,54 +274,65 @@ def prove_bench(sizes, quiet=False):
     return out
 
 
-def mapreduce_bench(leaves_per_rank=16, log_n=16, W=80):
-    """BASELINE configs[2]/[3] shape (skip / batch leaves): Map = one leaf proof per leaf, leaf i on
-    rank i % world; exchange = one all-gather of padded proofs (RCCL when launched under
-    torch.distributed.run, a no-op on one rank).  Leaf circuit = the build-defined circuit; the
-    recursive Reduce step is not built (DESIGN.md), so the time reported is map + gather."""
+def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=80):
+    """Map + exchange of a MapReduce proof on an already initialised process group: leaf i on rank
+    i % world, one all-gather of the padded proofs (RCCL on GPUs).  Every rank must call it; returns
+    the result dict (meaningful on rank 0)."""
     import importlib
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_leaves = leaves_per_rank * world                     # skip=1024 / batch=8 -> 128 leaves on 8 GPUs
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    pkg = graft.load_package()
     mr = importlib.import_module(graft.PKG_NAME + ".mapreduce")
     pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    n_leaves = leaves_per_rank * world                     # skip=1024 / batch=8 -> 128 leaves on 8 GPUs
     pr = pkg.Prover(local_rank)
     rc, circ, diag = pc.default_constants()
     pr.set_poseidon_constants(np.array(rc, dtype=np.uint64), np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64))
     consts, sigmas, wires = synthetic_circuit(pr, log_n, W)
     ck = pkg.PlonkCircuit(pr, consts, sigmas)
     dw = pr.to_device(wires)
+    dev = torch.device("cuda", local_rank) if world > 1 else None
     # warm-up: one leaf per rank through the whole map + gather path (first-use costs of the proof
     # pool, torch's host ops and the RCCL communicator are not part of a steady-state MapReduce)
-    mr.map_prove_gather(lambda i: ck.prove_(dw, 28, 16), world, padded_len=1 << 18,
-                        device=torch.device("cuda", local_rank) if world > 1 else None)
+    mr.map_prove_gather(lambda i: ck.prove_(dw, 28, 16), world, padded_len=1 << 18, device=dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    proofs = mr.map_prove_gather(lambda i: ck.prove_(dw, 28, 16), n_leaves, padded_len=1 << 18,
-                                 device=torch.device("cuda", local_rank) if world > 1 else None)
+    proofs = mr.map_prove_gather(lambda i: ck.prove_(dw, 28, 16), n_leaves, padded_len=1 << 18, device=dev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    if rank == 0:
-        print(json.dumps({"stage": "mapreduce_map+gather", "n_leaves": n_leaves, "leaf_log_n": log_n, "leaf_wires": W, "n_gpus": world,
-                          "seconds": round(dt, 4), "leaf_proof_bytes": len(proofs[0]), "all_present": all(len(p) > 0 for p in proofs),
-                          "note": "leaf = build-defined circuit; recursive reduce not built"}), flush=True)
+    res = {"stage": "mapreduce_map+gather", "n_leaves": n_leaves, "leaves_per_gpu": leaves_per_rank, "leaf_log_n": log_n,
+           "leaf_wires": W, "n_gpus": world, "seconds": round(dt, 4), "leaf_proofs_per_s": round(n_leaves / dt, 1),
+           "leaf_proof_bytes": len(proofs[0]), "all_present": all(len(p) > 0 for p in proofs),
+           "note": "BASELINE configs[2]/[3] shape with the build-defined leaf circuit (NOT upstream's); Map + one all-gather of "
+                   "padded proofs; the recursive Reduce step is not built"}
     dw.free()
     ck.free()
     pr.close()
+    return res
+
+
+def mapreduce_bench(leaves_per_rank=16, log_n=16, W=80):
+    """BASELINE configs[2]/[3] shape (skip / batch leaves): Map = one leaf proof per leaf, leaf i on
+    rank i % world; exchange = one all-gather of padded proofs (RCCL when launched under
+    torch.distributed.run, a no-op on one rank).  Leaf circuit = the build-defined circuit; the
+    recursive Reduce step is not built (DESIGN.md), so the time reported is map + gather."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    res = mapreduce_leg(graft.load_package(), rank, local_rank, world, leaves_per_rank, log_n, W)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -447,6 +458,15 @@ def main():
         out["prove"] = {"seconds": r["prove_s_best"], "circuit": r["circuit"], "log_n": 20, "wires": 80, "proof_bytes": r["proof_bytes"],
                         "queries": 28, "pow_bits": 16, "stage_ms": r["stage_ms"],
                         "note": "commit wires, Z/partial products, quotient, FRI openings; inputs resident in HBM"}
+    if not args.no_prove:
+        # ... and the MapReduce shape of CombinedSkip (configs[2]/[3]): 16 leaf proofs per GPU + one all-gather,
+        # on every rank.  A failure here must not cost the NTT line: it is reported instead.
+        try:
+            mrr = mapreduce_leg(pkg, rank, local_rank, world)
+        except Exception as e:  # noqa: BLE001
+            mrr = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if rank == 0:
+            out["mapreduce"] = mrr
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
