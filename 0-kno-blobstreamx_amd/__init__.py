@@ -34,7 +34,7 @@ class GlpError(RuntimeError):
 
 
 _ERR = {-1: "GLP_E_INVALID", -2: "GLP_E_NODEVICE", -3: "GLP_E_HIP", -4: "GLP_E_NOMEM",
-        -5: "GLP_E_UNSUPPORTED", -6: "GLP_E_STATE"}
+        -5: "GLP_E_UNSUPPORTED", -6: "GLP_E_STATE", -7: "GLP_E_REJECT"}
 
 _lib = None
 
@@ -74,6 +74,9 @@ def load_library():
         "glp_timer_start": (ctypes.c_int, [_vp]),
         "glp_timer_stop": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
         "glp_field_op": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_uint64]),
+        "glp_fri_verify": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32]),
+        "glp_plonk_verify": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32]),
+        "glp_plonk_circuit_cap": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_size_t)]),
         "glp_ntt": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]),
         "glp_ntt_ex": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64,
                                       ctypes.c_uint64, ctypes.c_uint32]),
@@ -459,6 +462,34 @@ class Prover:
         self.lib.glp_free_host(proof)
         return data
 
+    def _verify(self, what, call, proof):
+        """True = accepted, False = rejected (reason in self.last_reject); bad arguments raise"""
+        buf = np.frombuffer(bytes(proof) + b"", dtype=np.uint8)
+        if buf.size % 8 or buf.size == 0:
+            self.last_reject = "proof length is not a whole number of u64 words"
+            return False
+        words = np.frombuffer(buf.tobytes(), dtype="<u8").copy()          # 8-byte aligned copy
+        rc = call(words.ctypes.data, words.nbytes)
+        if rc == 0:
+            self.last_reject = None
+            return True
+        if rc == -7:
+            msg = self.lib.glp_last_error(self.ctx)
+            self.last_reject = msg.decode() if msg else "rejected"
+            return False
+        self._chk(rc, what)
+
+    def fri_verify(self, proof, min_queries=1, min_pow_bits=0):
+        """native verifier of a stand-alone FRI opening proof (glp_fri_verify)"""
+        return self._verify("glp_fri_verify", lambda p, n: self.lib.glp_fri_verify(self.ctx, p, n, min_queries, min_pow_bits), proof)
+
+    def plonk_verify(self, proof, circuit_cap=None, min_queries=1, min_pow_bits=0):
+        """native verifier of a PlonkCircuit proof; circuit_cap (PlonkCircuit.cap()) binds it to a circuit"""
+        cap = None if circuit_cap is None else np.ascontiguousarray(circuit_cap, dtype=np.uint64)
+        return self._verify("glp_plonk_verify",
+                            lambda p, n: self.lib.glp_plonk_verify(self.ctx, p, n, cap.ctypes.data if cap is not None else None,
+                                                                   cap.size if cap is not None else 0, min_queries, min_pow_bits), proof)
+
     def ed25519_witness(self, pubs, sigs, msgs):
         """pubs/sigs/msgs: lists of bytes.  Returns [n][37] u64 records (glprover.h)."""
         n = len(pubs)
@@ -533,6 +564,17 @@ class PlonkCircuit:
         prover._circuits.append(self)
         dc.free()
         ds.free()
+
+    def cap(self):
+        """the preprocessed commitment (constants + sigmas): the circuit's verifying key"""
+        n = ctypes.c_size_t(0)
+        self.prover._chk(self.prover.lib.glp_plonk_circuit_cap(self.h, None, ctypes.byref(n)), "glp_plonk_circuit_cap")
+        out = np.zeros(n.value, dtype=np.uint64)
+        self.prover._chk(self.prover.lib.glp_plonk_circuit_cap(self.h, out.ctypes.data, ctypes.byref(n)), "glp_plonk_circuit_cap")
+        return out
+
+    def verify(self, proof, min_queries=28, min_pow_bits=16):
+        return self.prover.plonk_verify(proof, self.cap(), min_queries, min_pow_bits)
 
     def prove(self, wires, num_queries=28, pow_bits=16):
         w = np.ascontiguousarray(wires, dtype=np.uint64)

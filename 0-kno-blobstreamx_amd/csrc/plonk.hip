@@ -102,6 +102,14 @@ extern "C" int glp_plonk_setup(glp_ctx* c, uint32_t log_n, uint32_t n_wires, con
 
 extern "C" void glp_plonk_free(glp_plonk_circuit* ck) { delete ck; }
 
+extern "C" int glp_plonk_circuit_cap(glp_plonk_circuit* ck, uint64_t* h_cap, size_t* n_words) {
+    if (!ck || !n_words || (!h_cap && *n_words)) return GLP_E_INVALID;
+    const size_t need = ck->pre.cap.size(), k = *n_words < need ? *n_words : need;
+    if (k) memcpy(h_cap, ck->pre.cap.data(), k * 8);
+    *n_words = need;
+    return GLP_OK;
+}
+
 extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, uint32_t num_queries, uint32_t pow_bits,
                                uint8_t** proof_out, size_t* proof_len) {
     if (!c) return GLP_E_INVALID;

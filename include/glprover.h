@@ -35,6 +35,7 @@ extern "C" {
 #define GLP_E_NOMEM -4
 #define GLP_E_UNSUPPORTED -5
 #define GLP_E_STATE -6       /* e.g. Poseidon constants not set */
+#define GLP_E_REJECT -7      /* a verifier rejected the proof (reason: glp_last_error) */
 
 #define GLP_NTT_INVERSE 1u   /* inverse transform, scaled by 1/n */
 #define GLP_NTT_BITREV 2u    /* write outputs in bit-reversed index order */
@@ -179,6 +180,22 @@ void glp_plonk_free(glp_plonk_circuit* ck);
  * proof (all batches at zeta, the Z batch also at w_n*zeta).  Free with glp_free_host. */
 int glp_plonk_prove(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, uint32_t num_queries, uint32_t pow_bits,
                     uint8_t** proof, size_t* proof_len);
+
+/* the circuit's preprocessed commitment (cap of the constants + sigmas batch) = its verifying key:
+ * copies min(*n_words, needed) u64 to h_cap and stores the needed count in *n_words */
+int glp_plonk_circuit_cap(glp_plonk_circuit* ck, uint64_t* h_cap, size_t* n_words);
+
+/* ---- verification (rows a5, a8, a12 from the consuming side; the Reduce step of row a11 as far as this
+ *      build goes; upstream names recalled: plonk::verifier::verify, fri::verifier::verify_fri_proof).
+ * Host arithmetic with the ctx's Poseidon constants (a verification is a few thousand permutations with
+ * a serial transcript).  proof: 8-byte aligned little-endian u64 words as written by the provers above.
+ * Returns GLP_OK when the proof is accepted, GLP_E_REJECT when it is not (glp_last_error says why),
+ * other codes for bad arguments.  min_queries / min_pow_bits: the security parameters the caller
+ * requires (a proof declaring fewer is rejected). */
+int glp_fri_verify(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, uint32_t min_queries, uint32_t min_pow_bits);
+/* h_circuit_cap (from glp_plonk_circuit_cap; may be NULL = do not bind to a circuit) */
+int glp_plonk_verify(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, const uint64_t* h_circuit_cap, size_t cap_words,
+                     uint32_t min_queries, uint32_t min_pow_bits);
 
 /* ---- witness generation (rows a9; upstream names recalled: curta SHA-256/SHA-512 chips) */
 /* n_msgs messages, each already padded to blocks_per_msg 64-byte blocks, [n_msgs][blocks*64].

@@ -1,14 +1,18 @@
-import os, sys, time, importlib
+"""profiles/mr_probe.py — measurement aid: where the time of a one-rank MapReduce goes
+(per-leaf prove, pack, gather/unpack, native verification)."""
+import importlib
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch
 import bench
 graft = bench.graft
-use_torch = len(sys.argv) > 1 and sys.argv[1] == "torch"
-if use_torch:
-    import torch
-    torch.cuda.set_device(0)
-    x = torch.zeros(4, device="cuda")
+torch.cuda.set_device(0)
 pkg = graft.load_package()
+mr = importlib.import_module(graft.PKG_NAME + ".mapreduce")
 pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
 pr = pkg.Prover(0)
 rc, circ, diag = pc.default_constants()
@@ -16,8 +20,14 @@ pr.set_poseidon_constants(np.array(rc, dtype=np.uint64), np.array(circ, dtype=np
 consts, sigmas, wires = bench.synthetic_circuit(pr, 16, 80)
 ck = pkg.PlonkCircuit(pr, consts, sigmas)
 dw = pr.to_device(wires)
-ck.prove_(dw, 28, 16)
-ts = []
-for i in range(16):
-    t0 = time.perf_counter(); p = ck.prove_(dw, 28, 16); ts.append(time.perf_counter() - t0)
-print("torch" if use_torch else "plain", "per-leaf ms:", [round(t * 1e3, 1) for t in ts], "total", round(sum(ts), 4))
+for rep in range(3):
+    t0 = time.perf_counter()
+    blobs = [(i, ck.prove_(dw, 28, 16)) for i in range(16)]
+    t1 = time.perf_counter()
+    packed = mr.pack_leaves(blobs, 1 << 18)
+    t2 = time.perf_counter()
+    proofs = mr.allgather_leaf_proofs(blobs, 16, 1 << 18)
+    t3 = time.perf_counter()
+    ok = all(ck.verify(p, 28, 16) for p in proofs)
+    t4 = time.perf_counter()
+    print(f"rep {rep}: prove {t1 - t0:.4f}  pack {t2 - t1:.4f}  gather {t3 - t2:.4f}  verify {t4 - t3:.4f} ok={ok}", flush=True)

@@ -32,6 +32,13 @@ def _worker(rank, world, port, n_leaves, q):
     ok = proofs == [fake_proof(i) for i in range(n_leaves)]
     # the map + exchange wrapper used by bench.py --mapreduce (prove_leaf stands in for PlonkCircuit.prove)
     ok = ok and mr.map_prove_gather(fake_proof, n_leaves, padded_len=200) == proofs
+    # Reduce: each rank checks the leaves proved by the next rank, verdicts combined by all-reduce(MIN);
+    # one bad leaf anywhere must flip the verdict on EVERY rank
+    checked = []
+    ok = ok and mr.reduce_verify(lambda p: (checked.append(p) or True), proofs) is True
+    ok = ok and checked == [fake_proof(i) for i in range((rank + 1) % world, n_leaves, world)]
+    bad_leaf = n_leaves - 1
+    ok = ok and mr.reduce_verify(lambda p: p != fake_proof(bad_leaf), proofs) is False
     # the bench's max-over-ranks time reduction
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -80,6 +80,7 @@ def test_prove_then_verify(setup, pkg, oracle, log_n, polys, rb, cap_h, a, fb, n
     proof = prover.fri_prove(list(batches), rb, cap_h, arity_bits=a, final_poly_bits=fb, num_queries=nq, pow_bits=pw)
     info = fv.parse_and_verify(proof, oracle)
     assert info["n_polys"] == polys and len(info["queries"]) == nq
+    assert prover.fri_verify(proof, min_queries=nq, min_pow_bits=pw), prover.last_reject     # native verifier
     # the claimed openings are the true evaluations: f(zeta) from the coefficients (oracle ifft)
     zeta = info["zeta"]
     k = 0
@@ -109,6 +110,7 @@ def test_two_opening_points(setup, pkg, oracle):
     g = pow(7, (P - 1) >> log_n, P)
     proof = prover.fri_prove([b0, b1], rb, cap_h, num_queries=10, pow_bits=6, point_mults=(1, g), open_masks=[1, 3])
     info = fv.parse_and_verify(proof, oracle)
+    assert prover.fri_verify(proof, 10, 6), prover.last_reject
     assert sorted(info["openings_at"].keys()) == [(0, 0), (0, 1), (1, 1)]
     co = v1.copy()
     oracle.orc_ntt(ptr(co), log_n, 3, 1)
@@ -145,7 +147,9 @@ def test_tampered_proofs_are_rejected(setup, pkg, oracle):
             rejected += 1
         except Exception:
             rejected += 1      # malformed sizes after a header flip count as rejection too
+        assert not prover.fri_verify(bad.tobytes()), f"native verifier accepted a proof with word {t} flipped"
     assert rejected == len(targets)
+    assert prover.fri_verify(proof, 8, 8) and not prover.fri_verify(proof[:-8]) and not prover.fri_verify(proof, 9, 8)
     with pytest.raises(fv.VerifyError):
         fv.parse_and_verify(proof[:-8], oracle)
     pb.free()

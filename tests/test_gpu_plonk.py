@@ -34,6 +34,15 @@ def test_prove_and_verify(setup, pkg, log_n, W, nq, pw):
     info = pref.verify_plonk(proof, oracle)
     assert info["log_n"] == log_n and info["W"] == W
     assert ck.prove(circ["wires"], num_queries=nq, pow_bits=pw) == proof      # deterministic
+    # the product's own (native) verifier agrees, bound to this circuit and to the security parameters
+    assert ck.verify(proof, min_queries=nq, min_pow_bits=pw), prover.last_reject
+    assert prover.plonk_verify(proof)                                         # unbound
+    assert not ck.verify(proof, min_queries=nq + 1, min_pow_bits=pw) and "fewer queries" in prover.last_reject
+    other = circ["consts"].copy()
+    other[1, 0] = (int(other[1, 0]) + 1) % P
+    ck2 = pkg.PlonkCircuit(prover, other, circ["sigmas"])                     # a different circuit: different key
+    assert not prover.plonk_verify(proof, ck2.cap()) and "preprocessed commitment" in prover.last_reject
+    ck2.free()
     ck.free()
 
 
@@ -60,6 +69,7 @@ def test_invalid_witness_cannot_be_proved(setup, pkg):
             continue
         with pytest.raises(fv.VerifyError):
             pref.verify_plonk(proof, oracle)
+        assert not ck.verify(proof, 8, 4)
     ck.free()
 
 
@@ -77,6 +87,9 @@ def test_tampered_plonk_proof_rejected(setup, pkg):
         bad[t] ^= np.uint64(1)
         with pytest.raises(Exception):
             pref.verify_plonk(bad.tobytes(), oracle)
+        assert not ck.verify(bad.tobytes(), 6, 4), f"native verifier accepted a proof with word {t} flipped"
+    assert ck.verify(proof, 6, 4)
+    assert not ck.verify(proof[:-8], 6, 4) and not ck.verify(proof + bytes(8), 6, 4)
     ck.free()
 
 
