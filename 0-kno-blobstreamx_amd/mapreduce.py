@@ -74,30 +74,49 @@ def allgather_leaf_proofs(local_blobs, n_leaves, padded_len, device=None):
 
 def map_prove_gather(prove_leaf, n_leaves, padded_len, device=None):
     """The Map + exchange steps of a MapReduce proof: this rank proves leaves
-    ``leaves_of_rank(n_leaves, rank, world)`` with ``prove_leaf(i) -> bytes`` (e.g.
+    ``leaves_of_rank(n_leaves, rank, world)`` with ``prove_leaf(i) -> bytes`` — or a LIST of such callables,
+    one per concurrent prover of this rank, each run by its own host thread — (e.g.
     ``PlonkCircuit.prove`` of the leaf circuit on leaf i's witness), then every rank receives all
     proofs in leaf order through ONE all-gather.  The Reduce step upstream is a tree of recursive
     verifier circuits; in this build the gathered proofs are checked by the host-side verifier
     (no in-circuit recursion yet — DESIGN.md §7), so what is returned is the ordered proof list."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    mine = [(i, prove_leaf(i)) for i in leaves_of_rank(n_leaves, rank, world)]
+    ids = leaves_of_rank(n_leaves, rank, world)
+    if callable(prove_leaf):
+        mine = [(i, prove_leaf(i)) for i in ids]
+    else:
+        # several provers on this GPU (one ctx = one stream each, driven by one host thread each): the
+        # launch- and latency-bound phases of one leaf proof (transcript round trips, the top Merkle levels,
+        # FRI queries) overlap with the throughput-bound phases of another.  ctypes releases the GIL.
+        from concurrent.futures import ThreadPoolExecutor
+        workers = list(prove_leaf)
+        with ThreadPoolExecutor(len(workers)) as ex:
+            futs = [ex.submit(lambda w=w, sub=ids[k::len(workers)]: [(i, w(i)) for i in sub]) for k, w in enumerate(workers)]
+            mine = sorted((p for f in futs for p in f.result()), key=lambda t: t[0])
     return allgather_leaf_proofs(mine, n_leaves, padded_len, device=device)
 
 
 def reduce_verify(verify_leaf, proofs, device=None):
     """The Reduce step as far as this build goes: every gathered leaf proof is checked by the native
-    verifier (``verify_leaf(proof_bytes) -> bool``, e.g. ``PlonkCircuit.verify``), the work split across
+    verifier (``verify_leaf(proof_bytes) -> bool``, e.g. ``PlonkCircuit.verify``, or a list of them — one per
+    ctx — run by one host thread each), the work split across
     ranks — rank r checks the leaves PROVED BY rank r+1 — and the verdicts are combined with one
     all-reduce(MIN).  Upstream folds the leaves with a tree of recursive verifier circuits into one
     proof; here the result is a boolean ("all leaves verify"), not a succinct proof."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     owner = (rank + 1) % world
-    ok = 1
-    for i in range(owner, len(proofs), world):
-        if not verify_leaf(proofs[i]):
-            ok = 0
+    ids = list(range(owner, len(proofs), world))
+    if callable(verify_leaf):
+        ok = int(all([verify_leaf(proofs[i]) for i in ids]))
+    else:
+        # a list of verifiers (one ctx each): host threads, the native verifier runs without the GIL
+        from concurrent.futures import ThreadPoolExecutor
+        vs = list(verify_leaf)
+        with ThreadPoolExecutor(len(vs)) as ex:
+            futs = [ex.submit(lambda v=v, sub=ids[k::len(vs)]: all([v(proofs[i]) for i in sub])) for k, v in enumerate(vs)]
+            ok = int(all([f.result() for f in futs]))
     if world > 1:
         t = torch.tensor([ok], dtype=torch.int32, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)

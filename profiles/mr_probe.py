@@ -31,3 +31,20 @@ for rep in range(3):
     ok = all(ck.verify(p, 28, 16) for p in proofs)
     t4 = time.perf_counter()
     print(f"rep {rep}: prove {t1 - t0:.4f}  pack {t2 - t1:.4f}  gather {t3 - t2:.4f}  verify {t4 - t3:.4f} ok={ok}", flush=True)
+
+# concurrent provers on one GPU: K ctxs, K host threads
+for K in (1, 2, 3, 4):
+    provers = [pr] + [pkg.Prover(0) for _ in range(K - 1)]
+    for q in provers[1:]:
+        q.set_poseidon_constants(np.array(rc, dtype=np.uint64), np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64))
+    cks = [ck] + [pkg.PlonkCircuit(q, consts, sigmas) for q in provers[1:]]
+    dws = [dw] + [q.to_device(wires) for q in provers[1:]]
+    workers = [(lambda i, c=c, d=d: c.prove_(d, 28, 16)) for c, d in zip(cks, dws)]
+    mr.map_prove_gather(workers, K, padded_len=1 << 18)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        proofs = mr.map_prove_gather(workers, 16, padded_len=1 << 18)
+        dt = time.perf_counter() - t0
+        print(f"K={K} rep {rep}: 16 leaves in {dt:.4f} s  ({16 / dt:.1f} leaves/s)  same={proofs[0] == proofs[5]}", flush=True)
+    for c, d, q in list(zip(cks, dws, provers))[1:]:
+        d.free(); c.free(); q.close()
