@@ -77,6 +77,7 @@ def load_library():
         "glp_fri_verify": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32]),
         "glp_plonk_verify": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32]),
         "glp_plonk_circuit_cap": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "glp_tm_merkle_root_var": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, _vp]),
         "glp_ntt": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]),
         "glp_ntt_ex": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64,
                                       ctypes.c_uint64, ctypes.c_uint32]),
@@ -520,6 +521,23 @@ class Prover:
         self._chk(self.lib.glp_tm_merkle_root(self.ctx, d.ptr if d else None, leaf_len, n, out), "glp_tm_merkle_root")
         if d:
             d.free()
+        return out.raw
+
+    def tm_merkle_root_var(self, leaves) -> bytes:
+        """Tendermint simple Merkle root of leaves of different lengths (a list of bytes)"""
+        n = len(leaves)
+        out = ctypes.create_string_buffer(32)
+        if n == 0:
+            self._chk(self.lib.glp_tm_merkle_root_var(self.ctx, None, None, 0, out), "glp_tm_merkle_root_var")
+            return out.raw
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in leaves])
+        blob = b"".join(leaves) or b"\0"
+        d = self.to_device(np.frombuffer(blob, dtype=np.uint8))
+        do = self.to_device(offs)
+        self._chk(self.lib.glp_tm_merkle_root_var(self.ctx, d.ptr, do.ptr, n, out), "glp_tm_merkle_root_var")
+        d.free()
+        do.free()
         return out.raw
 
     def transpose(self, mat):

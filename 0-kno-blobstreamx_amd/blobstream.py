@@ -1,0 +1,159 @@
+"""Host-side mirror of the circuit-level witness logic either side of the prover hot path
+(SURVEY.md §1b layers L4/L5, §8a rows a9/a10; BASELINE configs[0]): what a ``Circuit::define`` of
+CombinedStep / CombinedSkip / DataCommitment computes as WITNESS — validator-set hashing, signature
+verification, voting-power thresholds, the data-commitment Merkle root, and the packing of the public
+values — driven through the C ABI (SHA-256 Merkle and Ed25519 kernels).
+
+Everything here restates PUBLIC formats from memory, because the reference mount is empty
+(`/root/reference/.gitignore:1`, `changelog.md:1-2`): each item is tagged
+
+  [SPEC]      a published definition this follows (RFC 6962 Merkle trees, RFC 8032 Ed25519, protobuf
+              wire format, Solidity ABI encoding) and that the tests pin with independent Python code;
+  [RECALLED]  how upstream (tendermint / blobstreamx / tendermintx) uses it, recalled and UNVERIFIED —
+              never a parity claim.
+
+No CPU fallback: every hash and signature check below runs in the HIP kernels of libglprover.so.
+"""
+import struct
+
+import numpy as np
+
+# ---- encodings ---------------------------------------------------------------------------------
+
+
+def encode_varint(u: int) -> bytes:
+    """[SPEC] protobuf base-128 varint of a non-negative integer"""
+    if u < 0:
+        raise ValueError("negative varint")
+    out = bytearray()
+    while True:
+        b = u & 0x7F
+        u >>= 7
+        if u:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def encode_validator(pubkey: bytes, voting_power: int) -> bytes:
+    """[SPEC] protobuf wire format of  message SimpleValidator { PublicKey pub_key = 1; int64 voting_power = 2; }
+    with  message PublicKey { oneof sum { bytes ed25519 = 1; } }.
+    [RECALLED] this is the Merkle leaf of Tendermint's ValidatorSet.Hash()."""
+    if len(pubkey) != 32:
+        raise ValueError("ed25519 public key must be 32 bytes")
+    if not 0 <= voting_power < 2**63:
+        raise ValueError("voting power out of int64 range")
+    inner = b"\x0a" + encode_varint(32) + pubkey                     # PublicKey.ed25519
+    out = b"\x0a" + encode_varint(len(inner)) + inner                # SimpleValidator.pub_key
+    if voting_power:
+        out += b"\x10" + encode_varint(voting_power)                 # SimpleValidator.voting_power (omitted when 0)
+    return out
+
+
+def encode_data_root_tuple(height: int, data_root: bytes) -> bytes:
+    """[SPEC] Solidity abi.encode(uint256 height, bytes32 dataRoot): two 32-byte words.
+    [RECALLED] the leaf of Blobstream's data commitment (DataRootTuple)."""
+    if len(data_root) != 32 or not 0 <= height < 2**256:
+        raise ValueError("bad data root tuple")
+    return height.to_bytes(32, "big") + data_root
+
+
+# ---- hashing witnesses (GPU) -------------------------------------------------------------------
+
+
+def validator_set_hash(prover, pubkeys, voting_powers) -> bytes:
+    """Merkle root ([SPEC] RFC 6962 tree with 0x00 / 0x01 prefixes, as Tendermint's simple Merkle tree) of the
+    encoded validators — BASELINE configs[0]'s "validator-Merkle witness"."""
+    return prover.tm_merkle_root_var([encode_validator(k, p) for k, p in zip(pubkeys, voting_powers)])
+
+
+def data_commitment(prover, heights, data_roots) -> bytes:
+    """[RECALLED] Blobstream data commitment of a block range: the same Merkle tree over
+    abi.encode(height, dataRoot) for every block of the range (DataCommitmentCircuit's witness)."""
+    leaves = b"".join(encode_data_root_tuple(h, r) for h, r in zip(heights, data_roots))
+    return prover.tm_merkle_root(leaves, 64)
+
+
+# ---- signatures and voting power ---------------------------------------------------------------
+
+
+def verify_signatures(prover, pubkeys, signatures, sign_bytes):
+    """[SPEC] RFC 8032 Ed25519 verification of signatures[i] by pubkeys[i] over sign_bytes[i], all on the GPU
+    (glp_ed25519_witness: decoded points, k = SHA-512(R || A || M) mod L, [S]B and [k]A).  Entries whose
+    signature is None count as absent.  Returns (valid flags, witness records [n][37] u64)."""
+    n = len(pubkeys)
+    present = [i for i in range(n) if signatures[i] is not None]
+    valid = np.zeros(n, dtype=bool)
+    rec = np.zeros((n, 37), dtype=np.uint64)
+    if present:
+        out = prover.ed25519_witness([pubkeys[i] for i in present], [signatures[i] for i in present], [sign_bytes[i] for i in present])
+        for j, i in enumerate(present):
+            rec[i] = out[j]
+            valid[i] = bool(out[j][0])
+    return valid, rec
+
+
+def voting_power_check(voting_powers, signed, numerator, denominator):
+    """signed_power * denominator > total_power * numerator, in exact integers ([RECALLED] Tendermint's
+    "more than 2/3" commit rule and the light client's "more than 1/3 of the trusted set" skipping rule).
+    Returns (signed_power, total_power, ok)."""
+    total = int(sum(int(p) for p in voting_powers))
+    got = int(sum(int(p) for p, s in zip(voting_powers, signed) if s))
+    return got, total, got * denominator > total * numerator
+
+
+def skip_witness(prover, trusted_pubkeys, trusted_powers, target_pubkeys, target_powers, target_signatures, target_sign_bytes):
+    """The witness of a light-client skip ([RECALLED] tendermintx verify_skip, the core of CombinedSkipCircuit):
+      1. the target header's validators hash to `validators_hash` (committed in that header),
+      2. validators holding > 2/3 of the target set's power signed the target header,
+      3. signers that are also in the trusted set hold > 1/3 of the TRUSTED set's power.
+    target_signatures[i] is validator i's signature over target_sign_bytes[i] (its canonical vote; each
+    validator signs its own timestamp) or None."""
+    valid, rec = verify_signatures(prover, target_pubkeys, target_signatures, target_sign_bytes)
+    signed_power, total_power, two_thirds = voting_power_check(target_powers, valid, 2, 3)
+    trusted = {bytes(k): int(p) for k, p in zip(trusted_pubkeys, trusted_powers)}
+    overlap = sum(trusted.get(bytes(k), 0) for k, v in zip(target_pubkeys, valid) if v)
+    trusted_total = sum(trusted.values())
+    return {
+        "validators_hash": validator_set_hash(prover, target_pubkeys, target_powers),
+        "trusted_validators_hash": validator_set_hash(prover, trusted_pubkeys, trusted_powers),
+        "signature_valid": valid,
+        "signature_witness": rec,
+        "signed_power": signed_power,
+        "total_power": total_power,
+        "two_thirds_signed": two_thirds,
+        "trusted_power_signed": overlap,
+        "trusted_total_power": trusted_total,
+        "one_third_of_trusted_signed": overlap * 3 > trusted_total,
+        "accept": bool(two_thirds and overlap * 3 > trusted_total),
+    }
+
+
+# ---- public values ([RECALLED] plonky2x evm_read / evm_write: big-endian, tightly packed) ------
+
+
+def pack_skip_inputs(trusted_block: int, trusted_header_hash: bytes, target_block: int) -> bytes:
+    """uint64 ‖ bytes32 ‖ uint64 as abi.encodePacked"""
+    if len(trusted_header_hash) != 32:
+        raise ValueError("header hash must be 32 bytes")
+    return struct.pack(">Q", trusted_block) + trusted_header_hash + struct.pack(">Q", target_block)
+
+
+def pack_step_inputs(trusted_block: int, trusted_header_hash: bytes) -> bytes:
+    if len(trusted_header_hash) != 32:
+        raise ValueError("header hash must be 32 bytes")
+    return struct.pack(">Q", trusted_block) + trusted_header_hash
+
+
+def pack_outputs(target_header_hash: bytes, data_commitment_root: bytes) -> bytes:
+    """bytes32 ‖ bytes32"""
+    if len(target_header_hash) != 32 or len(data_commitment_root) != 32:
+        raise ValueError("outputs are two bytes32")
+    return target_header_hash + data_commitment_root
+
+
+def unpack_skip_inputs(b: bytes):
+    if len(b) != 48:
+        raise ValueError("skip inputs are 48 bytes")
+    return struct.unpack(">Q", b[:8])[0], b[8:40], struct.unpack(">Q", b[40:])[0]

@@ -221,9 +221,21 @@ extern "C" int glp_sha512_trace(glp_ctx* c, const uint8_t* d_blocks, uint64_t n_
 
 // Tendermint simple Merkle root of n fixed-size leaves (RFC 6962: 0x00/0x01 prefixes, split at the
 // largest power of two < n == pair adjacent nodes level by level, promoting an odd last node).
+static int tm_merkle_root_impl(glp_ctx* c, const uint8_t* d_leaves, uint32_t leaf_len, const uint64_t* d_offsets, uint64_t n, uint8_t* h_root32);
+
 extern "C" int glp_tm_merkle_root(glp_ctx* c, const uint8_t* d_leaves, uint32_t leaf_len, uint64_t n, uint8_t* h_root32) {
     if (!c) return GLP_E_INVALID;
     if (!h_root32 || (!d_leaves && n) || leaf_len == 0 || leaf_len > 118 || n > (1ull << 31)) { glp_set_err(c, "glp_tm_merkle_root: bad argument"); return GLP_E_INVALID; }
+    return tm_merkle_root_impl(c, d_leaves, leaf_len, nullptr, n, h_root32);
+}
+// leaves of different lengths: leaf i = d_data[d_offsets[i] .. d_offsets[i+1]) (n + 1 non-decreasing offsets on the device)
+extern "C" int glp_tm_merkle_root_var(glp_ctx* c, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t n, uint8_t* h_root32) {
+    if (!c) return GLP_E_INVALID;
+    if (!h_root32 || ((!d_data || !d_offsets) && n) || n > (1ull << 31)) { glp_set_err(c, "glp_tm_merkle_root_var: bad argument"); return GLP_E_INVALID; }
+    return tm_merkle_root_impl(c, d_data, 0, d_offsets, n, h_root32);
+}
+
+static int tm_merkle_root_impl(glp_ctx* c, const uint8_t* d_leaves, uint32_t leaf_len, const uint64_t* d_offsets, uint64_t n, uint8_t* h_root32) {
     if (n == 0) {   // SHA256("")
         static const uint8_t e[32] = {0xe3,0xb0,0xc4,0x42,0x98,0xfc,0x1c,0x14,0x9a,0xfb,0xf4,0xc8,0x99,0x6f,0xb9,0x24,0x27,0xae,0x41,0xe4,0x64,0x9b,0x93,0x4c,0xa4,0x95,0x99,0x1b,0x78,0x52,0xb8,0x55};
         memcpy(h_root32, e, 32);
@@ -235,7 +247,8 @@ extern "C" int glp_tm_merkle_root(glp_ctx* c, const uint8_t* d_leaves, uint32_t 
     GLP_HIPCHK(c, hipMalloc((void**)&a, n * 32));
     hipError_t e2 = hipMalloc((void**)&b, ((n + 1) / 2) * 32);
     if (e2 != hipSuccess) { hipFree(a); glp_set_err(c, "glp_tm_merkle_root: alloc"); return GLP_E_NOMEM; }
-    hipLaunchKernelGGL(glp_tm_leaf_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_leaves, leaf_len, n, a, c->hash->d_k256);
+    if (d_offsets) hipLaunchKernelGGL(glp_tm_leaf_var_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_leaves, d_offsets, n, a, c->hash->d_k256);
+    else hipLaunchKernelGGL(glp_tm_leaf_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_leaves, leaf_len, n, a, c->hash->d_k256);
     u64 cnt = n;
     u32 *src = a, *dst = b;
     while (cnt > 1) {

@@ -396,6 +396,37 @@ __global__ void __launch_bounds__(256) glp_tm_leaf_kernel(const uint8_t* __restr
     for (int k = 0; k < 8; k++) out[i * 8 + k] = h[k];
 }
 
+// the same for leaves of DIFFERENT lengths (protobuf-encoded validators, header fields): leaf i is
+// data[offsets[i] .. offsets[i+1]), any length
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_tm_leaf_var_kernel(const uint8_t* __restrict__ data, const u64* __restrict__ offsets, u64 n,
+                                                              u32* __restrict__ out, const u32* __restrict__ k256) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = data + offsets[i];
+    const u64 total = offsets[i + 1] - offsets[i] + 1;     // with the 0x00 prefix
+    const u64 nblk = (total + 9 + 63) / 64;
+    u32 h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    for (u64 b = 0; b < nblk; b++) {
+        u32 m[16];
+        for (int wd = 0; wd < 16; wd++) {
+            u32 v = 0;
+            for (int k = 0; k < 4; k++) {
+                const u64 pos = b * 64 + wd * 4 + k;      // byte position in the padded message
+                u32 byte = 0;
+                if (pos == 0) byte = 0x00;
+                else if (pos < total) byte = p[pos - 1];
+                else if (pos == total) byte = 0x80;
+                else if (pos >= nblk * 64 - 8) { const u64 bits = total * 8; byte = (u32)(bits >> (8 * (nblk * 64 - 1 - pos))) & 0xff; }
+                v = (v << 8) | byte;
+            }
+            m[wd] = v;
+        }
+        glp_sha256_compress_words(h, m, k256);
+    }
+    for (int k = 0; k < 8; k++) out[i * 8 + k] = h[k];
+}
+
 // one level: out[i] = SHA256(0x01 || in[2i] || in[2i+1]) for i < n/2; an odd last node is promoted.
 // The 65-byte message is two blocks.
 template <int UNUSED = 0>

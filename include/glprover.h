@@ -219,6 +219,9 @@ int glp_ed25519_witness(glp_ctx* ctx, const uint8_t* d_pubs, const uint8_t* d_si
 /* Tendermint "simple" Merkle root (RFC 6962 prefixes) of n leaves of leaf_len (<= 118) bytes each:
  * the validator-set / header hashing of BASELINE configs[0].  Synchronous; h_root32 = 32 bytes. */
 int glp_tm_merkle_root(glp_ctx* ctx, const uint8_t* d_leaves, uint32_t leaf_len, uint64_t n, uint8_t* h_root32);
+/* the same tree over leaves of different lengths (protobuf-encoded validators, header fields):
+ * leaf i = d_data[d_offsets[i] .. d_offsets[i+1]), n + 1 non-decreasing byte offsets (device) */
+int glp_tm_merkle_root_var(glp_ctx* ctx, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t n, uint8_t* h_root32);
 
 /* Multi-GPU (row a11 / SURVEY §8e): leaf subproofs shard one per GPU; the all-gather of the
  * padded proof blobs is done by the host through torch.distributed (RCCL) — see bench.py /

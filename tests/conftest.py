@@ -128,6 +128,7 @@ def emu():
     lib.emu_bitrev_scale.argtypes = [u64p, u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]
     lib.emu_ed25519_witness.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
                                         ctypes.c_void_p, ctypes.c_void_p]
+    lib.emu_tm_merkle_root_var.argtypes = [ctypes.c_char_p, u64p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_char_p]
     lib.emu_tm_merkle_root.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_char_p]
     return lib
 

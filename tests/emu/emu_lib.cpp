@@ -339,6 +339,21 @@ extern "C" int emu_tm_merkle_root(const uint8_t* leaves, u32 leaf_len, u64 n, co
     return 0;
 }
 
+extern "C" int emu_tm_merkle_root_var(const uint8_t* data, const u64* offsets, u64 n, const u32* k256, uint8_t* root32) {
+    std::vector<u32> a(n * 8 + 8), b(((n + 1) / 2) * 8 + 8);
+    glp_emu_launch((unsigned)((n + 63) / 64), 64, 0, [&] { glp_tm_leaf_var_kernel<0>(data, offsets, n, a.data(), k256); });
+    u64 cnt = n;
+    u32 *src = a.data(), *dst = b.data();
+    while (cnt > 1) {
+        const u64 nout = (cnt + 1) / 2;
+        glp_emu_launch((unsigned)((nout + 63) / 64), 64, 0, [&] { glp_tm_inner_kernel<0>(src, cnt, dst, k256); });
+        cnt = nout;
+        std::swap(src, dst);
+    }
+    for (int k = 0; k < 8; k++) { root32[4*k] = src[k] >> 24; root32[4*k+1] = src[k] >> 16; root32[4*k+2] = src[k] >> 8; root32[4*k+3] = src[k]; }
+    return 0;
+}
+
 // ---- Ed25519 witness kernel (row a10) under emulation -----------------------------------------
 #include "../../0-kno-blobstreamx_amd/csrc/ed25519_kernels.cuh"
 extern "C" int emu_ed25519_witness(const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, u32 msg_stride, const u32* lens, u64 n,
