@@ -70,6 +70,7 @@ def load_library():
         "glp_d2h": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
         "glp_sync": (ctypes.c_int, [_vp]),
         "glp_trim_pool": (ctypes.c_int, [_vp]),
+        "glp_bind_thread": (ctypes.c_int, [_vp]),
         "glp_set_stream": (ctypes.c_int, [_vp, _vp]),
         "glp_timer_start": (ctypes.c_int, [_vp]),
         "glp_timer_stop": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
@@ -213,6 +214,10 @@ class Prover:
     def to_device(self, arr):
         a = np.ascontiguousarray(arr)
         return DeviceBuffer(self, max(a.nbytes, 8)).upload(a)
+
+    def bind_thread(self):
+        """call once from a worker thread before driving this prover from it (HIP's current device is per thread)"""
+        self._chk(self.lib.glp_bind_thread(self.ctx), "glp_bind_thread")
 
     def sync(self):
         self._chk(self.lib.glp_sync(self.ctx), "glp_sync")

@@ -460,6 +460,7 @@ uint8_t* glp_words_to_blob(const std::vector<u64>& P, size_t* len) {
 extern "C" int glp_fri_prove(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batch* batches, uint32_t n_batches,
                              uint8_t** proof_out, size_t* proof_len) {
     if (!c) return GLP_E_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return GLP_E_HIP;   // the current device is per host thread: callers may drive ctxs from worker threads
     if (!cfg || !batches || n_batches == 0 || !proof_out || !proof_len) { glp_set_err(c, "glp_fri_prove: null argument"); return GLP_E_INVALID; }
     *proof_out = nullptr; *proof_len = 0;
     glp_challenger* chp = challenger_new(c);

@@ -56,12 +56,27 @@ GL_HD void glp_static_for(F&& f) {
 
 GL_HD u64 gl_make64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
+// x + y (mod 2^64) for a 32-bit y: v_mad_u64_u32(y, 1, x) — one 4.2-cycle op instead of the v_mov (to pair y
+// with a zero register) + v_lshl_add_u64 the compiler emits for `x + (u64)y`
+GL_HD u64 gl_add_u32(u64 x, u32 y) {
+#if GLP_ASM_FIELD
+    u64 r, junk;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(r), "=s"(junk) : "v"(y), "v"(x));
+    return r;
+#else
+    return x + (u64)y;
+#endif
+}
+
 // canonical a + b.  (A 5-VALU lane-mask form of the fix-up measured the same as this select form on
-// the NTT passes, 1560 vs 1563 GB/s A/B in one run, so the portable form stays.)
+// the NTT passes, 1560 vs 1563 GB/s A/B in one run, so the select form stays.)
 GL_HD u64 gl_add(u64 a, u64 b) {
     const u64 s = a + b;
     const bool over = (s < a) | (s >= GL_P);     // true sum >= p
-    return s + (over ? GL_EPS : 0ULL);            // - p  (mod 2^64)
+    // "+ (u64)m" here stays v_mov + v_lshl_add_u64: gl_add_u32's v_mad form measured 2 % SLOWER on the NTT passes
+    // (1594 vs 1624 GB/s, three alternating runs) — the butterflies are dependent add chains and the mad's latency
+    // shows; in the products and folds (independent lanes) it is a gain (Poseidon tree 54.6 -> 51.3 ms)
+    return s + (over ? GL_EPS : 0ULL);                // - p  (mod 2^64)
 }
 
 // a - b (+ p on borrow), valid for any u64 a and b <= p; canonical when a is
@@ -99,19 +114,22 @@ GL_HD u64 gl_mad_eps(u32 w, u64 t) {
             "v_cmp_le_u64 %2, %6, %0\n\t"
             "s_or_b64 %1, %1, %2\n\t"
             "s_nop 0\n\t"
-            "v_cndmask_b32 %3, 0, -1, %1"
-            : "=&v"(r), "=&s"(C), "=&s"(G), "=v"(m)
+            "v_cndmask_b32 %3, 0, -1, %1\n\t"
+            "v_mad_u64_u32 %0, %2, %3, 1, %0"              // r += m (m = eps or 0), as one op
+            : "=&v"(r), "=&s"(C), "=&s"(G), "=&v"(m)
             : "v"(w), "v"(t), "s"(GL_P)
             : "scc");
     } else {
-        asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
+        u64 J;
+        asm("v_mad_u64_u32 %0, %1, %4, -1, %5\n\t"
             "s_nop 1\n\t"
-            "v_cndmask_b32 %2, 0, -1, %1"
-            : "=&v"(r), "=&s"(C), "=v"(m)
+            "v_cndmask_b32 %2, 0, -1, %1\n\t"
+            "v_mad_u64_u32 %0, %3, %2, 1, %0"
+            : "=&v"(r), "=&s"(C), "=&v"(m), "=&s"(J)
             : "v"(w), "v"(t));
     }
     // wrapped: r <= 2^64 - 2^33, so + eps neither overflows nor reaches p; else r - p < 2^32
-    return r + (u64)m;
+    return r;
 #else
     const u64 t1 = ((u64)w << 32) - w;
     u64 r;
@@ -161,7 +179,7 @@ GL_HD u64 gl_mul_t(u64 a, u64 b) {
     const u64 p0 = (u64)a0 * b0;
     const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
     const u64 p2 = (u64)a1 * b0 + (u32)p1;
-    const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    const u64 p3 = gl_add_u32((u64)a1 * b1 + (p1 >> 32), (u32)(p2 >> 32));   // < 2^64: the product is < 2^128
     return gl_reduce128_t<CANON>(p3, (p2 << 32) | (u32)p0);
 }
 GL_HD u64 gl_mul(u64 a, u64 b) { return gl_mul_t<true>(a, b); }
@@ -178,11 +196,12 @@ GL_HD u64 gl_fold_small(u64 al, u64 ah) {
     asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
         "s_or_b64 %1, %1, %5\n\t"
         "s_nop 0\n\t"
-        "v_cndmask_b32 %2, 0, -1, %1"
-        : "=&v"(v), "=&s"(C2), "=v"(m)
+        "v_cndmask_b32 %2, 0, -1, %1\n\t"
+        "v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "=&v"(v), "=&s"(C2), "=&v"(m)
         : "v"((u32)(ah >> 32)), "v"(gl_make64((u32)al, lh)), "s"(C1)
         : "scc");
-    return v + (u64)m;
+    return v;
 #else
     const u64 l = al + (ah << 32);
     const bool c1 = l < al;

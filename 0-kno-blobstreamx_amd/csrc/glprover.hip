@@ -287,6 +287,14 @@ extern "C" int glp_create(glp_ctx** out, int device_id) {
     return GLP_OK;
 }
 
+// HIP's current device is a per-thread setting: a host thread other than the one that created the ctx
+// must bind before its first call (glp_plonk_prove / glp_fri_prove / glp_plonk_setup bind by themselves)
+extern "C" int glp_bind_thread(glp_ctx* c) {
+    if (!c) return GLP_E_INVALID;
+    GLP_HIPCHK(c, hipSetDevice(c->device));
+    return GLP_OK;
+}
+
 extern "C" void glp_destroy(glp_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);

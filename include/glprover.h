@@ -55,6 +55,10 @@ int glp_sync(glp_ctx* ctx);
 /* the prover drivers keep their temporaries in a ctx-owned pool (reused across proofs, no hipFree on
  * the hot path); this returns every cached block to the driver (GLP_POOL_CAP_MB caps the cache) */
 int glp_trim_pool(glp_ctx* ctx);
+/* A ctx may be driven by a host thread other than its creator (still one thread at a time per ctx); HIP's
+ * current device is per thread, so such a thread calls this once before its first call on the ctx.
+ * glp_plonk_setup / glp_plonk_prove / glp_fri_prove bind by themselves. */
+int glp_bind_thread(glp_ctx* ctx);
 /* adopt an external hipStream_t (e.g. torch's current stream); NULL restores the ctx's own */
 int glp_set_stream(glp_ctx* ctx, void* hip_stream);
 /* HIP-event timer on the ctx's stream: start, enqueue work, stop -> elapsed milliseconds */
