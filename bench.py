@@ -274,6 +274,31 @@ def prove_bench(sizes, quiet=False):
     return out
 
 
+def _rehearsal():
+    """GLP_BENCH_REHEARSE=1: run the multi-rank code path on ONE GPU — every rank on cuda:0, gloo collectives on host
+    tensors — to rehearse rank guards, barriers and the MapReduce exchange where only one GPU is available.  Its
+    numbers mean nothing (the ranks share a GPU); the driver's multi-GPU runs use RCCL ("nccl") as always."""
+    return os.environ.get("GLP_BENCH_REHEARSE") == "1"
+
+
+def _init_dist(local_rank):
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if _rehearsal():
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+
+def _gpu_index(local_rank):
+    return 0 if _rehearsal() else local_rank
+
+
+def _coll_device():
+    return "cpu" if _rehearsal() else "cuda"
+
+
 def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=80, provers_per_gpu=3):
     """Map + exchange + Reduce of a MapReduce proof on an already initialised process group: leaf i on rank
     i % world, `provers_per_gpu` concurrent provers per GPU (one ctx = one stream = one host thread each:
@@ -291,7 +316,7 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
     provers, cks, dws = [], [], []
     consts = sigmas = wires = None
     for k in range(provers_per_gpu):
-        pr = pkg.Prover(local_rank)
+        pr = pkg.Prover(_gpu_index(local_rank))
         pr.set_poseidon_constants(np.array(rc, dtype=np.uint64), np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64))
         if consts is None:
             consts, sigmas, wires = synthetic_circuit(pr, log_n, W)
@@ -300,7 +325,7 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
         dws.append(pr.to_device(wires))
     workers = [(lambda i, c=c, d=d: c.prove_(d, 28, 16)) for c, d in zip(cks, dws)]
     verifiers = [(lambda p, c=c: c.verify(p, 28, 16)) for c in cks]
-    dev = torch.device("cuda", local_rank) if world > 1 else None
+    dev = torch.device("cuda", local_rank) if (world > 1 and not _rehearsal()) else None
     # warm-up: one leaf per prover through the whole map + gather path (first-use costs of the proof
     # pools, torch's host ops and the RCCL communicator are not part of a steady-state MapReduce)
     mr.map_prove_gather(workers, provers_per_gpu * world, padded_len=1 << 18, device=dev)
@@ -316,7 +341,7 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
     all_ok = mr.reduce_verify(verifiers, proofs, device=dev)
     dt_red = time.perf_counter() - t1
     if world > 1:
-        tt = torch.tensor([dt, dt_red], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, dt_red], dtype=torch.float64, device=_coll_device())
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, dt_red = float(tt[0].item()), float(tt[1].item())
     res = {"stage": "mapreduce", "n_leaves": n_leaves, "leaves_per_gpu": leaves_per_rank, "leaf_log_n": log_n,
@@ -343,10 +368,9 @@ def mapreduce_bench(leaves_per_rank=16, log_n=16, W=80):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(_gpu_index(local_rank))
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        _init_dist(local_rank)
     res = mapreduce_leg(graft.load_package(), rank, local_rank, world, leaves_per_rank, log_n, W)
     if rank == 0:
         print(json.dumps(res), flush=True)
@@ -386,13 +410,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(_gpu_index(local_rank))
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        _init_dist(local_rank)
 
     pkg = graft.load_package()
-    pr = pkg.Prover(local_rank)
+    pr = pkg.Prover(_gpu_index(local_rank))
     log_n, batch = args.log_n, args.batch
     n = 1 << log_n
 
@@ -417,7 +440,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([wall], dtype=torch.float64, device=_coll_device())
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
     ms_per_step = wall * 1e3 / args.steps
