@@ -120,6 +120,7 @@ int gather(glp_ctx* c, const u64* d_src, const std::vector<u64>& offs, u64* h_ou
 extern "C" int glp_eval_at_ext(glp_ctx* c, const uint64_t* d_coeffs, uint64_t poly_stride, uint32_t log_n, uint32_t n_polys,
                                const uint64_t* h_z, uint64_t* h_out) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!d_coeffs || !h_z || !h_out || log_n > 30 || poly_stride < (1ull << log_n) || h_z[0] >= GL_P || h_z[1] >= GL_P) {
         glp_set_err(c, "glp_eval_at_ext: bad argument");
         return GLP_E_INVALID;
@@ -133,6 +134,7 @@ extern "C" int glp_eval_at_ext(glp_ctx* c, const uint64_t* d_coeffs, uint64_t po
 
 extern "C" int glp_pow_grind(glp_ctx* c, const uint64_t* h_seed4, uint32_t pow_bits, uint64_t* h_nonce) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!h_seed4 || !h_nonce || pow_bits > 40) { glp_set_err(c, "glp_pow_grind: bad argument"); return GLP_E_INVALID; }
     if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set"); return GLP_E_STATE; }
     if (pow_bits == 0) { *h_nonce = 0; return GLP_OK; }
@@ -460,7 +462,7 @@ uint8_t* glp_words_to_blob(const std::vector<u64>& P, size_t* len) {
 extern "C" int glp_fri_prove(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batch* batches, uint32_t n_batches,
                              uint8_t** proof_out, size_t* proof_len) {
     if (!c) return GLP_E_INVALID;
-    if (hipSetDevice(c->device) != hipSuccess) return GLP_E_HIP;   // the current device is per host thread: callers may drive ctxs from worker threads
+    GLP_BIND(c);
     if (!cfg || !batches || n_batches == 0 || !proof_out || !proof_len) { glp_set_err(c, "glp_fri_prove: null argument"); return GLP_E_INVALID; }
     *proof_out = nullptr; *proof_len = 0;
     glp_challenger* chp = challenger_new(c);

@@ -82,6 +82,14 @@ struct GlpPoolBuf {
 };
 void glp_hash_destroy(glp_ctx* c);
 
+// HIP's current device is a per-host-thread setting and a ctx may be driven from a worker thread (MapReduce map
+// step: several ctxs per GPU, one thread each): every entry point re-selects the ctx's device (a no-op when it
+// already is current)
+#define GLP_BIND(c)                                                        \
+    do {                                                                   \
+        if (hipSetDevice((c)->device) != hipSuccess) return GLP_E_HIP;     \
+    } while (0)
+
 #define GLP_HIPCHK(c, expr)                                                                    \
     do {                                                                                       \
         hipError_t e__ = (expr);                                                               \

@@ -67,6 +67,7 @@ void glp_pool_trim(glp_ctx* c) {
 }
 extern "C" int glp_trim_pool(glp_ctx* c) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     glp_pool_trim(c);
     return GLP_OK;
 }
@@ -291,7 +292,7 @@ extern "C" int glp_create(glp_ctx** out, int device_id) {
 // must bind before its first call (glp_plonk_prove / glp_fri_prove / glp_plonk_setup bind by themselves)
 extern "C" int glp_bind_thread(glp_ctx* c) {
     if (!c) return GLP_E_INVALID;
-    GLP_HIPCHK(c, hipSetDevice(c->device));
+    GLP_BIND(c);
     return GLP_OK;
 }
 
@@ -320,12 +321,14 @@ extern "C" const char* glp_last_error(const glp_ctx* c) { return c ? c->err : "n
 
 extern "C" int glp_alloc(glp_ctx* c, void** d_ptr, size_t bytes) {
     if (!c || !d_ptr) return GLP_E_INVALID;
+    GLP_BIND(c);
     hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
     if (e != hipSuccess) { glp_set_err(c, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return GLP_E_NOMEM; }
     return GLP_OK;
 }
 extern "C" int glp_free(glp_ctx* c, void* d_ptr) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!d_ptr) return GLP_OK;
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     GLP_HIPCHK(c, hipFree(d_ptr));
@@ -333,28 +336,33 @@ extern "C" int glp_free(glp_ctx* c, void* d_ptr) {
 }
 extern "C" int glp_h2d(glp_ctx* c, void* d, const void* h, size_t bytes) {
     if (!c || (!d && bytes) || (!h && bytes)) return GLP_E_INVALID;
+    GLP_BIND(c);
     GLP_HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     return GLP_OK;
 }
 extern "C" int glp_d2h(glp_ctx* c, void* h, const void* d, size_t bytes) {
     if (!c || (!d && bytes) || (!h && bytes)) return GLP_E_INVALID;
+    GLP_BIND(c);
     GLP_HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     return GLP_OK;
 }
 extern "C" int glp_sync(glp_ctx* c) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     return GLP_OK;
 }
 extern "C" int glp_set_stream(glp_ctx* c, void* s) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return GLP_OK;
 }
 extern "C" int glp_timer_start(glp_ctx* c) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     GLP_HIPCHK(c, hipEventRecord(c->t0, c->stream));
     return GLP_OK;
 }
@@ -407,6 +415,7 @@ extern "C" int glp_ntt_describe_plan(glp_ctx* c, uint32_t log_n, uint32_t batch,
 
 extern "C" int glp_set_profiling(glp_ctx* c, int on) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     c->profiling = on ? 1 : 0;
     c->last_npass = 0;
     return GLP_OK;
@@ -440,6 +449,7 @@ extern "C" int glp_last_pass_ms(glp_ctx* c, float* ms, int* n_out) {
 int glp_ntt_impl(glp_ctx* c, const uint64_t* src, uint64_t* dst, uint32_t log_n, uint32_t batch, uint64_t ss, uint64_t ds,
                  uint32_t flags) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!src || !dst || log_n > 32 || (flags & ~(GLP_NTT_INVERSE | GLP_NTT_BITREV))) { glp_set_err(c, "glp_ntt: bad argument"); return GLP_E_INVALID; }
     const u64 n = 1ull << log_n;
     if (batch > 1 && (ss < n || ds < n)) { glp_set_err(c, "glp_ntt: poly stride < n"); return GLP_E_INVALID; }
@@ -496,6 +506,7 @@ extern "C" int glp_ntt(glp_ctx* c, uint64_t* d_io, uint32_t log_n, uint32_t batc
 extern "C" int glp_lde_coset(glp_ctx* c, const uint64_t* coeffs, uint64_t* out, uint32_t log_n, uint32_t rate_bits,
                              uint32_t batch, uint64_t shift, uint32_t flags) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!coeffs || !out || log_n + rate_bits > 32 || shift == 0 || shift >= GL_P || (flags & ~GLP_NTT_BITREV)) {
         glp_set_err(c, "glp_lde_coset: bad argument");
         return GLP_E_INVALID;
@@ -555,6 +566,7 @@ extern "C" int glp_lde_coset(glp_ctx* c, const uint64_t* coeffs, uint64_t* out, 
 
 extern "C" int glp_field_op(glp_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint64_t n) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (op < 0 || op > 10 || ((!a || !out || (!b && op != 4)) && n)) { glp_set_err(c, "glp_field_op: bad argument"); return GLP_E_INVALID; }
     if (n == 0) return GLP_OK;
     u64 blocks = (n + 255) / 256;
@@ -566,6 +578,7 @@ extern "C" int glp_field_op(glp_ctx* c, int op, const uint64_t* a, const uint64_
 
 extern "C" int glp_transpose(glp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t rows, uint64_t cols) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!in || !out || in == out) { glp_set_err(c, "glp_transpose: bad argument"); return GLP_E_INVALID; }
     if (rows == 0 || cols == 0) return GLP_OK;
     const u64 tr = (rows + 31) / 32, tc = (cols + 31) / 32;

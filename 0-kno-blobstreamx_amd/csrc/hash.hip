@@ -59,6 +59,7 @@ static GlpPoseidonConsts consts_of(glp_hash_state* h) { return glp_dev_consts(h)
 
 extern "C" int glp_set_poseidon_constants(glp_ctx* c, const uint64_t* rc, size_t n_rc, const uint64_t* circ, const uint64_t* diag) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!rc || !circ || !diag || n_rc != 360) { glp_set_err(c, "glp_set_poseidon_constants: need 360 round constants, 12 + 12 MDS entries"); return GLP_E_INVALID; }
     std::vector<u64> all(384);
     for (int i = 0; i < 360; i++) { if (rc[i] >= GL_P) { glp_set_err(c, "round constant %d not canonical", i); return GLP_E_INVALID; } all[i] = rc[i]; }
@@ -102,6 +103,7 @@ static int need_consts(glp_ctx* c) {
 
 extern "C" int glp_poseidon_permute(glp_ctx* c, uint64_t* d_states, uint64_t n) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!d_states && n) { glp_set_err(c, "glp_poseidon_permute: null states"); return GLP_E_INVALID; }
     int rc = need_consts(c);
     if (rc) return rc;
@@ -118,6 +120,7 @@ extern "C" int glp_poseidon_permute(glp_ctx* c, uint64_t* d_states, uint64_t n) 
 static int merkle_impl(glp_ctx* c, const u64* src, u64 stride, bool poly_major, u32 leaf_len, u32 log_leaves, u32 cap_h,
                        u64* digests, u64* h_cap) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!src || !digests || log_leaves > 40 || cap_h > log_leaves || leaf_len == 0) { glp_set_err(c, "glp_merkle: bad argument"); return GLP_E_INVALID; }
     int rc = need_consts(c);
     if (rc) return rc;
@@ -166,6 +169,7 @@ extern "C" int glp_merkle_from_polys(glp_ctx* c, const uint64_t* d_polys, uint64
 extern "C" int glp_fri_fold2(glp_ctx* c, const uint64_t* d_evals, uint64_t* d_out, uint32_t log_n, uint64_t shift,
                              const uint64_t* h_beta) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!d_evals || !d_out || !h_beta || log_n == 0 || log_n > 32 || shift == 0 || shift >= GL_P || h_beta[0] >= GL_P || h_beta[1] >= GL_P) {
         glp_set_err(c, "glp_fri_fold2: bad argument");
         return GLP_E_INVALID;
@@ -194,6 +198,7 @@ static int ensure_sha_tables(glp_ctx* c) {
 extern "C" int glp_sha256_trace(glp_ctx* c, const uint8_t* d_blocks, uint64_t n_msgs, uint32_t bpm, uint32_t* d_digests,
                                 uint32_t* d_trace) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if ((!d_blocks || !d_digests) && n_msgs) { glp_set_err(c, "glp_sha256_trace: null buffer"); return GLP_E_INVALID; }
     if (n_msgs == 0) return GLP_OK;
     if (bpm == 0 || (n_msgs + 63) / 64 > 0x7fffffffull) { glp_set_err(c, "glp_sha256_trace: bad size"); return GLP_E_INVALID; }
@@ -208,6 +213,7 @@ extern "C" int glp_sha256_trace(glp_ctx* c, const uint8_t* d_blocks, uint64_t n_
 extern "C" int glp_sha512_trace(glp_ctx* c, const uint8_t* d_blocks, uint64_t n_msgs, uint32_t bpm, uint64_t* d_digests,
                                 uint64_t* d_trace) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if ((!d_blocks || !d_digests) && n_msgs) { glp_set_err(c, "glp_sha512_trace: null buffer"); return GLP_E_INVALID; }
     if (n_msgs == 0) return GLP_OK;
     if (bpm == 0 || (n_msgs + 63) / 64 > 0x7fffffffull) { glp_set_err(c, "glp_sha512_trace: bad size"); return GLP_E_INVALID; }
@@ -225,12 +231,14 @@ static int tm_merkle_root_impl(glp_ctx* c, const uint8_t* d_leaves, uint32_t lea
 
 extern "C" int glp_tm_merkle_root(glp_ctx* c, const uint8_t* d_leaves, uint32_t leaf_len, uint64_t n, uint8_t* h_root32) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!h_root32 || (!d_leaves && n) || leaf_len == 0 || leaf_len > 118 || n > (1ull << 31)) { glp_set_err(c, "glp_tm_merkle_root: bad argument"); return GLP_E_INVALID; }
     return tm_merkle_root_impl(c, d_leaves, leaf_len, nullptr, n, h_root32);
 }
 // leaves of different lengths: leaf i = d_data[d_offsets[i] .. d_offsets[i+1]) (n + 1 non-decreasing offsets on the device)
 extern "C" int glp_tm_merkle_root_var(glp_ctx* c, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t n, uint8_t* h_root32) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if (!h_root32 || ((!d_data || !d_offsets) && n) || n > (1ull << 31)) { glp_set_err(c, "glp_tm_merkle_root_var: bad argument"); return GLP_E_INVALID; }
     return tm_merkle_root_impl(c, d_data, 0, d_offsets, n, h_root32);
 }
@@ -272,6 +280,7 @@ static int tm_merkle_root_impl(glp_ctx* c, const uint8_t* d_leaves, uint32_t lea
 extern "C" int glp_ed25519_witness(glp_ctx* c, const uint8_t* d_pubs, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_stride,
                                    const uint32_t* d_lens, uint64_t n, uint64_t* d_out) {
     if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
     if ((!d_pubs || !d_sigs || !d_msgs || !d_lens || !d_out) && n) { glp_set_err(c, "glp_ed25519_witness: null buffer"); return GLP_E_INVALID; }
     if (n == 0) return GLP_OK;
     if (msg_stride == 0 || n > (1ull << 30)) { glp_set_err(c, "glp_ed25519_witness: bad size"); return GLP_E_INVALID; }

@@ -62,7 +62,7 @@ static int commit_values(glp_ctx* c, u64* d_vals_owned, u32 n_polys, u32 log_n, 
 extern "C" int glp_plonk_setup(glp_ctx* c, uint32_t log_n, uint32_t n_wires, const uint64_t* d_const_vals, const uint64_t* d_sigma_vals,
                                uint32_t rate_bits, uint32_t cap_height, glp_plonk_circuit** out) {
     if (!c) return GLP_E_INVALID;
-    if (hipSetDevice(c->device) != hipSuccess) return GLP_E_HIP;   // the current device is per host thread: callers may drive ctxs from worker threads
+    GLP_BIND(c);
     if (!out || !d_const_vals || !d_sigma_vals || log_n < 3 || log_n > 24 || n_wires == 0 || n_wires % 8 || n_wires > 128 || rate_bits != 3 ||
         cap_height > 12) {
         glp_set_err(c, "glp_plonk_setup: unsupported shape (W %% 8 == 0, W <= 128, rate_bits == 3)");
@@ -114,7 +114,7 @@ extern "C" int glp_plonk_circuit_cap(glp_plonk_circuit* ck, uint64_t* h_cap, siz
 extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, uint32_t num_queries, uint32_t pow_bits,
                                uint8_t** proof_out, size_t* proof_len) {
     if (!c) return GLP_E_INVALID;
-    if (hipSetDevice(c->device) != hipSuccess) return GLP_E_HIP;   // the current device is per host thread: callers may drive ctxs from worker threads
+    GLP_BIND(c);
     if (!ck || !d_wire_vals || !proof_out || !proof_len || num_queries == 0 || num_queries > 256 || pow_bits > 32) {
         glp_set_err(c, "glp_plonk_prove: bad argument");
         return GLP_E_INVALID;

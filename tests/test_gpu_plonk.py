@@ -111,3 +111,31 @@ def test_stage_timing_tree(setup, pkg):
     assert all(ms >= 0 for _, ms in stages)
     assert prover.last_stage_ms() == stages          # stable until the next prove
     ck.free()
+
+
+def test_provers_driven_from_worker_threads(pkg):
+    """the MapReduce map step drives several ctxs on one GPU from one host thread each: proofs made concurrently
+    on worker threads are byte-identical to the one made on the main thread, and every one verifies"""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(42)
+    circ = pref.build_circuit(rng, 9, 16)
+    rc, cc, dg = poseidon_consts("small")
+    provers, cks = [], []
+    for _ in range(3):
+        pr = pkg.Prover(0)
+        pr.set_poseidon_constants(rc, cc, dg)
+        provers.append(pr)
+        cks.append(pkg.PlonkCircuit(pr, circ["consts"], circ["sigmas"]))
+    want = cks[0].prove(circ["wires"], 8, 4)
+
+    def job(k):
+        provers[k].bind_thread()
+        return [cks[k].prove(circ["wires"], 8, 4) for _ in range(4)]
+
+    with ThreadPoolExecutor(3) as ex:
+        got = [p for f in [ex.submit(job, k) for k in range(3)] for p in f.result()]
+    assert all(p == want for p in got)
+    assert all(cks[i % 3].verify(p, 8, 4) for i, p in enumerate(got))
+    for ck, pr in zip(cks, provers):
+        ck.free()
+        pr.close()
