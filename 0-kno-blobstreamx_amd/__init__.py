@@ -79,6 +79,10 @@ def load_library():
         "glp_plonk_verify": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32]),
         "glp_plonk_circuit_cap": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_size_t)]),
         "glp_tm_merkle_root_var": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, _vp]),
+        "glp_fri_verify_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p,
+                                               ctypes.c_size_t]),
+        "glp_plonk_verify_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_uint32,
+                                                 ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]),
         "glp_ntt": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]),
         "glp_ntt_ex": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64,
                                       ctypes.c_uint64, ctypes.c_uint32]),
@@ -131,6 +135,38 @@ def load_library():
             fn.argtypes = args
     _lib = lib
     return lib
+
+
+def _host_verify(fn_name, constants, proof, extra, min_queries, min_pow_bits):
+    """(accepted, reason) from the ctx-less verifiers: works on a host without a GPU"""
+    lib = load_library()
+    rc, circ, diag = (np.ascontiguousarray(a, dtype=np.uint64) for a in constants)
+    if rc.size != 360 or circ.size != 12 or diag.size != 12:
+        raise GlpError("Poseidon constants: 360 round constants, 12 + 12 MDS entries")
+    raw = bytes(proof)
+    if len(raw) % 8 or not raw:
+        return False, "proof length is not a whole number of u64 words"
+    words = np.frombuffer(raw, dtype="<u8").copy()
+    err = ctypes.create_string_buffer(256)
+    rcode = getattr(lib, fn_name)(rc.ctypes.data, circ.ctypes.data, diag.ctypes.data, words.ctypes.data, words.nbytes, *extra,
+                                  min_queries, min_pow_bits, err, 256)
+    if rcode == 0:
+        return True, None
+    if rcode == -7:
+        return False, err.value.decode()
+    raise GlpError(f"{fn_name}: {_ERR.get(rcode, rcode)}")
+
+
+def fri_verify_host(constants, proof, min_queries=1, min_pow_bits=0):
+    """verify a FRI opening proof without a GPU or a ctx; constants = (rc[360], mds_circ[12], mds_diag[12])"""
+    return _host_verify("glp_fri_verify_host", constants, proof, (), min_queries, min_pow_bits)
+
+
+def plonk_verify_host(constants, proof, circuit_cap=None, min_queries=1, min_pow_bits=0):
+    """verify a circuit proof without a GPU or a ctx; circuit_cap binds it to a circuit (PlonkCircuit.cap())"""
+    cap = None if circuit_cap is None else np.ascontiguousarray(circuit_cap, dtype=np.uint64)
+    extra = (cap.ctypes.data if cap is not None else None, cap.size if cap is not None else 0)
+    return _host_verify("glp_plonk_verify_host", constants, proof, extra, min_queries, min_pow_bits)
 
 
 class DeviceBuffer:

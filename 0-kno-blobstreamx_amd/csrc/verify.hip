@@ -13,6 +13,7 @@
 // tests/fri_verifier.py and tests/plonk_ref.py (Python big-int) stay the independent checkers of
 // both the prover and this file.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <string.h>
 #include <vector>
 #include "glp_ctx.h"
@@ -25,8 +26,14 @@ const u64 PLONK_TAG = 0x31304B4C504C4747ull;
 const u32 CHUNK = 8, NCHAL = 2;
 
 struct Reject {
-    glp_ctx* c;
-    int fail(const char* why) { glp_set_err(c, "proof rejected: %s", why); return GLP_E_REJECT; }
+    glp_ctx* c;          // reason goes to the ctx's error text ...
+    char* buf;           // ... or, for the ctx-less entry points, to the caller's buffer (may be null)
+    size_t n;
+    int fail(const char* why) {
+        if (c) glp_set_err(c, "proof rejected: %s", why);
+        else if (buf && n) snprintf(buf, n, "proof rejected: %s", why);
+        return GLP_E_REJECT;
+    }
 };
 
 struct Hasher {
@@ -105,9 +112,8 @@ struct FriInfo {
 };
 
 // The FRI opening proof starting at rd.pos, continuing the transcript `ch` (fresh for a stand-alone proof).
-int fri_verify(glp_ctx* c, const Hasher& h, glp_challenger& ch, Reader& rd, bool allow_trailing, u32 min_queries, u32 min_pow_bits,
+int fri_verify(Reject rj, const Hasher& h, glp_challenger& ch, Reader& rd, bool allow_trailing, u32 min_queries, u32 min_pow_bits,
                FriInfo& fi) {
-    Reject rj{c};
     const u64* hd;
     if (!rd.take(11, &hd)) return rj.fail("truncated");
     const u64 tag = hd[0], log_n = hd[1], rb = hd[2], cap0 = hd[3], a = hd[4], fb = hd[5], nq = hd[6], pow_bits = hd[7], shift = hd[8],
@@ -304,14 +310,36 @@ int fri_verify(glp_ctx* c, const Hasher& h, glp_challenger& ch, Reader& rd, bool
     return GLP_OK;
 }
 
-bool make_hasher(glp_ctx* c, Hasher& h, glp_challenger& ch) {
-    if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set (glp_set_poseidon_constants)"); return false; }
-    h.consts = c->hash->h_consts;
-    h.small_mds = c->hash->small_mds;
+void init_hasher(const std::vector<u64>& consts, bool small_mds, Hasher& h, glp_challenger& ch) {
+    h.consts = consts;
+    h.small_mds = small_mds;
     memset(ch.state, 0, sizeof(ch.state));
     ch.n_in = ch.n_out = 0;
-    ch.consts = h.consts;
-    ch.small_mds = h.small_mds;
+    ch.consts = consts;
+    ch.small_mds = small_mds;
+}
+bool make_hasher(glp_ctx* c, Hasher& h, glp_challenger& ch) {
+    if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set (glp_set_poseidon_constants)"); return false; }
+    init_hasher(c->hash->h_consts, c->hash->small_mds, h, ch);
+    return true;
+}
+// constants passed explicitly (the ctx-less entry points): same validity rules as glp_set_poseidon_constants
+bool make_hasher_from(const u64* rc, const u64* circ, const u64* diag, Hasher& h, glp_challenger& ch) {
+    if (!rc || !circ || !diag) return false;
+    std::vector<u64> all(384);
+    for (int i = 0; i < 360; i++) { if (rc[i] >= GL_P) return false; all[i] = rc[i]; }
+    unsigned __int128 sum = 0;
+    u64 maxdiag = 0;
+    bool small = true;
+    for (int i = 0; i < 12; i++) {
+        if (circ[i] >= GL_P || diag[i] >= GL_P) return false;
+        all[360 + i] = circ[i]; all[372 + i] = diag[i];
+        sum += circ[i];
+        if (diag[i] > maxdiag) maxdiag = diag[i];
+        if (circ[i] >> 24 || diag[i] >> 24) small = false;
+    }
+    if (sum + maxdiag >= ((unsigned __int128)1 << 24)) small = false;
+    init_hasher(all, small, h, ch);
     return true;
 }
 
@@ -350,25 +378,17 @@ gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 W, const std::ve
 }
 }  // namespace
 
-extern "C" int glp_fri_verify(glp_ctx* c, const uint8_t* proof, size_t len, uint32_t min_queries, uint32_t min_pow_bits) {
-    if (!c) return GLP_E_INVALID;
-    if (!proof || len == 0 || len % 8 || ((uintptr_t)proof & 7)) { glp_set_err(c, "glp_fri_verify: bad argument (proof must be 8-byte aligned words)"); return GLP_E_INVALID; }
-    Hasher h;
-    glp_challenger ch;
-    if (!make_hasher(c, h, ch)) return GLP_E_STATE;
+static bool proof_args_ok(const uint8_t* proof, size_t len) { return proof && len && len % 8 == 0 && ((uintptr_t)proof & 7) == 0; }
+
+static int fri_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, const uint8_t* proof, size_t len, uint32_t min_queries,
+                            uint32_t min_pow_bits) {
     Reader rd{(const u64*)proof, len / 8, 0};
     FriInfo fi;
-    return fri_verify(c, h, ch, rd, false, min_queries, min_pow_bits, fi);
+    return fri_verify(rj, h, ch, rd, false, min_queries, min_pow_bits, fi);
 }
 
-extern "C" int glp_plonk_verify(glp_ctx* c, const uint8_t* proof, size_t len, const uint64_t* h_circuit_cap, size_t cap_words,
-                                uint32_t min_queries, uint32_t min_pow_bits) {
-    if (!c) return GLP_E_INVALID;
-    if (!proof || len == 0 || len % 8 || ((uintptr_t)proof & 7)) { glp_set_err(c, "glp_plonk_verify: bad argument (proof must be 8-byte aligned words)"); return GLP_E_INVALID; }
-    Reject rj{c};
-    Hasher h;
-    glp_challenger ch;
-    if (!make_hasher(c, h, ch)) return GLP_E_STATE;
+static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, const uint8_t* proof, size_t len, const uint64_t* h_circuit_cap,
+                              size_t cap_words, uint32_t min_queries, uint32_t min_pow_bits) {
     Reader rd{(const u64*)proof, len / 8, 0};
     auto take_obs = [&](size_t k, const u64** out) -> bool {
         if (!rd.take(k, out)) return false;
@@ -393,7 +413,7 @@ extern "C" int glp_plonk_verify(glp_ctx* c, const uint8_t* proof, size_t len, co
     for (u32 t = 0; t < NCHAL; t++) alpha[t] = ch.challenge();
     if (!take_obs(capw, &cap_q)) return rj.fail("truncated");
     FriInfo fi;
-    int rc = fri_verify(c, h, ch, rd, false, min_queries, min_pow_bits, fi);
+    int rc = fri_verify(rj, h, ch, rd, false, min_queries, min_pow_bits, fi);
     if (rc != GLP_OK) return rc;
     // the FRI part must be about exactly these commitments, shapes and points
     const u64 want_polys[4] = {3 + W, W, (u64)NCHAL * M, (u64)NCHAL << rb};
@@ -434,4 +454,43 @@ extern "C" int glp_plonk_verify(glp_ctx* c, const uint8_t* proof, size_t len, co
         if (!ext_eq(lhs, gl_ext_mul(zh, tz))) return rj.fail("PLONK identity fails at zeta");
     }
     return GLP_OK;
+}
+
+extern "C" int glp_fri_verify(glp_ctx* c, const uint8_t* proof, size_t len, uint32_t min_queries, uint32_t min_pow_bits) {
+    if (!c) return GLP_E_INVALID;
+    if (!proof_args_ok(proof, len)) { glp_set_err(c, "glp_fri_verify: bad argument (proof must be 8-byte aligned words)"); return GLP_E_INVALID; }
+    Hasher h;
+    glp_challenger ch;
+    if (!make_hasher(c, h, ch)) return GLP_E_STATE;
+    return fri_verify_entry(Reject{c, nullptr, 0}, h, ch, proof, len, min_queries, min_pow_bits);
+}
+
+extern "C" int glp_plonk_verify(glp_ctx* c, const uint8_t* proof, size_t len, const uint64_t* h_circuit_cap, size_t cap_words,
+                                uint32_t min_queries, uint32_t min_pow_bits) {
+    if (!c) return GLP_E_INVALID;
+    if (!proof_args_ok(proof, len)) { glp_set_err(c, "glp_plonk_verify: bad argument (proof must be 8-byte aligned words)"); return GLP_E_INVALID; }
+    Hasher h;
+    glp_challenger ch;
+    if (!make_hasher(c, h, ch)) return GLP_E_STATE;
+    return plonk_verify_entry(Reject{c, nullptr, 0}, h, ch, proof, len, h_circuit_cap, cap_words, min_queries, min_pow_bits);
+}
+
+// The same verifiers for a host WITHOUT a GPU (a light client, CI): no ctx, the Poseidon constants are passed
+// explicitly (360 + 12 + 12 words, the arguments of glp_set_poseidon_constants); err (may be NULL) receives the reason.
+extern "C" int glp_fri_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* proof, size_t len,
+                                   uint32_t min_queries, uint32_t min_pow_bits, char* err, size_t err_len) {
+    if (err && err_len) err[0] = 0;
+    Hasher h;
+    glp_challenger ch;
+    if (!proof_args_ok(proof, len) || !make_hasher_from(h_rc, h_mds_circ, h_mds_diag, h, ch)) return GLP_E_INVALID;
+    return fri_verify_entry(Reject{nullptr, err, err_len}, h, ch, proof, len, min_queries, min_pow_bits);
+}
+extern "C" int glp_plonk_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* proof, size_t len,
+                                     const uint64_t* h_circuit_cap, size_t cap_words, uint32_t min_queries, uint32_t min_pow_bits, char* err,
+                                     size_t err_len) {
+    if (err && err_len) err[0] = 0;
+    Hasher h;
+    glp_challenger ch;
+    if (!proof_args_ok(proof, len) || !make_hasher_from(h_rc, h_mds_circ, h_mds_diag, h, ch)) return GLP_E_INVALID;
+    return plonk_verify_entry(Reject{nullptr, err, err_len}, h, ch, proof, len, h_circuit_cap, cap_words, min_queries, min_pow_bits);
 }

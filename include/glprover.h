@@ -201,6 +201,15 @@ int glp_fri_verify(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, uint3
 int glp_plonk_verify(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, const uint64_t* h_circuit_cap, size_t cap_words,
                      uint32_t min_queries, uint32_t min_pow_bits);
 
+/* The same two verifiers for a host WITHOUT a GPU (a light client, CI): no ctx — the Poseidon constants are
+ * passed explicitly (the arguments of glp_set_poseidon_constants: 360, 12, 12 words) and err (may be NULL)
+ * receives the rejection reason.  GLP_E_INVALID for unusable arguments or non-canonical constants. */
+int glp_fri_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
+                        size_t proof_len, uint32_t min_queries, uint32_t min_pow_bits, char* err, size_t err_len);
+int glp_plonk_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
+                          size_t proof_len, const uint64_t* h_circuit_cap, size_t cap_words, uint32_t min_queries,
+                          uint32_t min_pow_bits, char* err, size_t err_len);
+
 /* ---- witness generation (rows a9; upstream names recalled: curta SHA-256/SHA-512 chips) */
 /* n_msgs messages, each already padded to blocks_per_msg 64-byte blocks, [n_msgs][blocks*64].
  * d_digests: [n_msgs][8] u32 (big-endian words as u32).  d_trace (may be NULL):

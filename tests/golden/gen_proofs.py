@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""tests/golden/gen_proofs.py — writes tests/golden/proofs.json ON AN MI355X: one proof of the build-defined
+circuit and one stand-alone FRI opening proof, made by the GPU prover from seeded inputs, with the package's
+default Poseidon constants.  The fixtures pin the proof bytes (transcript order, arithmetic, layout): the GPU
+tests regenerate them and demand identical bytes; the CPU tests verify them with the native host verifier and the
+independent Python verifiers.  Usage (GPU box, repo root):  python tests/golden/gen_proofs.py"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+import __graft_entry__ as graft  # noqa: E402
+import plonk_ref as pref  # noqa: E402
+from conftest import poseidon_consts, rand_field  # noqa: E402
+
+PLONK = {"seed": 20261004, "log_n": 6, "W": 8, "queries": 8, "pow_bits": 4}
+FRI = {"seed": 77001, "log_n": 8, "polys": [3, 2], "rate_bits": 3, "cap_height": 2, "arity_bits": 2, "final_poly_bits": 3, "queries": 6,
+       "pow_bits": 5}
+
+
+def make(pkg, prover):
+    rc, circ, diag = poseidon_consts("small")
+    prover.set_poseidon_constants(rc, circ, diag)
+    c = pref.build_circuit(np.random.default_rng(PLONK["seed"]), PLONK["log_n"], PLONK["W"])
+    ck = pkg.PlonkCircuit(prover, c["consts"], c["sigmas"])
+    plonk_proof = ck.prove(c["wires"], PLONK["queries"], PLONK["pow_bits"])
+    cap = ck.cap()
+    ck.free()
+    rng = np.random.default_rng(FRI["seed"])
+    batches = [pkg.PolynomialBatch.from_values(prover, rand_field(rng, (k, 1 << FRI["log_n"])), FRI["rate_bits"], FRI["cap_height"])
+               for k in FRI["polys"]]
+    fri_proof = prover.fri_prove(batches, FRI["rate_bits"], FRI["cap_height"], arity_bits=FRI["arity_bits"],
+                                 final_poly_bits=FRI["final_poly_bits"], num_queries=FRI["queries"], pow_bits=FRI["pow_bits"])
+    for b in batches:
+        b.free()
+    return {"note": "made by tests/golden/gen_proofs.py on an MI355X; Poseidon constants = poseidon_constants.default_constants()",
+            "plonk": dict(PLONK, circuit_cap=[int(v) for v in cap], proof=plonk_proof.hex()),
+            "fri": dict(FRI, proof=fri_proof.hex())}
+
+
+if __name__ == "__main__":
+    pkg = graft.load_package()
+    pr = pkg.Prover(0)
+    out = make(pkg, pr)
+    pr.close()
+    with open(os.path.join(HERE, "proofs.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote proofs.json:", len(out["plonk"]["proof"]) // 2, "+", len(out["fri"]["proof"]) // 2, "bytes")
