@@ -74,6 +74,29 @@ def time_ntt(pr, d, log_n, batch, steps, warmup):
     return ms / steps
 
 
+def effective_cpus():
+    """CPUs this job may actually use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box
+    shows 256 hardware threads but grants a 16-CPU quota per GPU; 256 OpenMP threads under that quota only
+    oversubscribe it)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:     # cgroup v1
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(log_n, seconds_target=15.0):
     """the CPU oracle (kind "port": the in-repo restatement; the Rust plonky2 prover cannot be
     built here) on a bounded sample: `polys` transforms of size 2^log_n, OpenMP over the batch."""
@@ -81,6 +104,8 @@ def cpu_baseline(log_n, seconds_target=15.0):
     u64p = ctypes.POINTER(ctypes.c_uint64)
     orc.orc_ntt_fast.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint64, ctypes.c_int]
     orc.orc_num_threads.restype = ctypes.c_int
+    orc.orc_set_num_threads.argtypes = [ctypes.c_int]
+    orc.orc_set_num_threads(effective_cpus())
     cores = orc.orc_num_threads()
     n = 1 << log_n
     probe = splitmix_fill(n * cores, 1).reshape(cores, n)
@@ -95,7 +120,8 @@ def cpu_baseline(log_n, seconds_target=15.0):
     dt = time.perf_counter() - t
     return {"value": round(16.0 * n * polys / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
             "sample": f"{polys} forward NTTs of 2^{log_n} (16*n bytes each) by oracle/gl_fast.c (hand-reduced radix-2, "
-                      f"gcc -O3 -march=native), OpenMP over the batch, {dt:.1f} s"}
+                      f"gcc -O3 -march=native), OpenMP over the batch on {cores} threads = the job's CPU quota "
+                      f"({os.cpu_count()} hardware threads visible), {dt:.1f} s"}
 
 
 SWEEP = {

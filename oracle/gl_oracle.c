@@ -54,6 +54,15 @@ int orc_num_threads(void) {
 #endif
 }
 
+/* cap the OpenMP team (bench.py: the box's cgroup CPU quota, not its core count, is what the job may use) */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------ NTT (row a2) */
 /* definition, O(n^2): the pin for the fast transform below */
 void orc_dft_naive(const uint64_t *x, uint64_t *out, unsigned log_n, int inverse) {
