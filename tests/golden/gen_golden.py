@@ -114,6 +114,20 @@ def main():
         tm["cases"].append({"n": n, "leaves": b"".join(leaves).hex(), "root": tm_root(leaves).hex()})
     dump("tendermint_merkle.json", tm)
 
+    # coset LDE with BIT-REVERSED output at the sizes the by-cosets path serves (log_n >= 6): values[i] =
+    # f(shift * w_N^bitrev(i)).  Own generator so that the files above keep their bytes.
+    rnd2 = random.Random(0xB17AE5)
+    ldeb = {"cases": []}
+    for log_n, rate_bits, shift in ((6, 1, 7), (7, 3, 7), (8, 3, 7), (8, 2, 0x123456789ABCDEF)):
+        n, log_N = 1 << log_n, log_n + rate_bits
+        c = [rnd2.randrange(P) for _ in range(n)]
+        padded = [c[j] * pow(shift, j, P) % P for j in range(n)] + [0] * ((n << rate_bits) - n)
+        nat = dft(padded)
+        rev = [nat[int(format(i, f"0{log_N}b")[::-1], 2)] for i in range(1 << log_N)]
+        ldeb["cases"].append({"log_n": log_n, "rate_bits": rate_bits, "shift": str(shift), "coeffs": [str(v) for v in c],
+                              "values_bitrev": [str(v) for v in rev]})
+    dump("lde_bitrev.json", ldeb)
+
 
 if __name__ == "__main__":
     main()

@@ -100,6 +100,18 @@ def test_emulated_coset_lde_bitrev_vs_oracle(emu, oracle, log_n, rb, batch, plan
     assert np.array_equal(src, coeffs)
 
 
+def test_emulated_coset_lde_bitrev_vs_golden(emu):
+    """the by-cosets LDE under emulation against the committed big-int vectors (no oracle in the loop)"""
+    with open(os.path.join(G, "lde_bitrev.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        coeffs = np.array([int(v) for v in c["coeffs"]], dtype=np.uint64)
+        want = np.array([int(v) for v in c["values_bitrev"]], dtype=np.uint64)
+        out = np.zeros(len(want), dtype=np.uint64)
+        assert emu.emu_lde_coset_bitrev(ptr(coeffs), ptr(out), c["log_n"], c["rate_bits"], 1, int(c["shift"]), None) == 0
+        assert np.array_equal(out, want), (c["log_n"], c["rate_bits"])
+
+
 def test_emulated_ntt_strided_batch(emu, oracle):
     """polynomials embedded in wider rows (stride > n) on both sides"""
     rng = np.random.default_rng(5)

@@ -37,6 +37,13 @@ def test_golden_vectors(prover):
         coeffs = np.array([int(v) for v in c["coeffs"]], dtype=np.uint64)
         want = np.array([int(v) for v in c["values"]], dtype=np.uint64)
         assert np.array_equal(prover.lde(coeffs, c["rate_bits"], int(c["shift"])), want)
+    # bit-reversed output = the by-cosets path (size-n transforms per coset, scale fused into the first pass)
+    with open(os.path.join(G, "lde_bitrev.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        coeffs = np.array([int(v) for v in c["coeffs"]], dtype=np.uint64)
+        want = np.array([int(v) for v in c["values_bitrev"]], dtype=np.uint64)
+        assert np.array_equal(prover.lde(coeffs, c["rate_bits"], int(c["shift"]), bitrev=True), want), (c["log_n"], c["rate_bits"])
 
 
 @pytest.mark.parametrize("log_n", list(range(0, 21)))

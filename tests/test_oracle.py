@@ -70,6 +70,17 @@ def test_lde_matches_golden(oracle):
         assert np.array_equal(out, want)
 
 
+def test_lde_bitrev_matches_golden(oracle):
+    """the oracle's LDE + bit reversal against the big-int vectors of the bit-reversed layout"""
+    for c in load("lde_bitrev.json")["cases"]:
+        coeffs = np.array([int(v) for v in c["coeffs"]], dtype=np.uint64)
+        want = np.array([int(v) for v in c["values_bitrev"]], dtype=np.uint64)
+        out = np.zeros(len(want), dtype=np.uint64)
+        oracle.orc_lde_coset(ptr(coeffs), ptr(out), c["log_n"], c["rate_bits"], 1, int(c["shift"]))
+        oracle.orc_bitrev_rows(ptr(out), c["log_n"] + c["rate_bits"], 1)
+        assert np.array_equal(out, want)
+
+
 def test_sha2_known_answers(oracle):
     oracle.orc_sha256.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_void_p]
     oracle.orc_sha512.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_void_p]
