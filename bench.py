@@ -325,6 +325,42 @@ def _coll_device():
     return "cpu" if _rehearsal() else "cuda"
 
 
+def prove_stage_detail(stage_ms, log_n, W, rate_bits=3, cap_h=4):
+    """per-stage work of one proof of the build-defined circuit and the rate it was done at (SURVEY.md §5:
+    one line per stage with ms, bytes moved, GB/s / permutations per second).  Bytes are ALGORITHMIC (each operand
+    column read once, each result column written once); permutations = leaf sponges + tree nodes."""
+    n, N = 1 << log_n, 1 << (log_n + rate_bits)
+    M = W // 8
+    cols = {"pre": 3 + W, "wires": W, "zs": 2 * M, "quotient": 2 << rate_bits}
+
+    def commit(k):     # ifft + LDE by cosets + Merkle of k polynomials
+        perms = N * ((k + 7) // 8 if k > 4 else 0) + (N - (1 << cap_h))
+        byts = 16 * n * k + 8 * n * k + 8 * N * k + 8 * N * k          # ifft r+w, LDE read + write, leaf-hash read
+        return perms, byts
+
+    out = {}
+    for name, ms in stage_ms.items():
+        d = {"ms": round(ms, 3)}
+        if name.startswith("commit_wires"):
+            d["perms"], d["bytes"] = commit(cols["wires"])
+        elif name.startswith("commit_zs"):
+            d["perms"], d["bytes"] = commit(cols["zs"])
+        elif name.startswith("commit_quotient"):
+            d["perms"], d["bytes"] = commit(cols["quotient"])
+        elif name.startswith("perm_products"):
+            d["bytes"] = 8 * n * (2 * W + cols["zs"])
+        elif name.startswith("quotient(K7)"):
+            d["bytes"] = 8 * N * (cols["pre"] + W + cols["zs"] + 2) + 8 * N * 2
+        elif name == "fri:combine":
+            d["bytes"] = 8 * N * (cols["pre"] + W + cols["zs"] + cols["quotient"]) + 16 * N
+        if "bytes" in d and ms > 0:
+            d["GBps"] = round(d["bytes"] / (ms * 1e-3) / 1e9, 1)
+        if "perms" in d and ms > 0:
+            d["Gperm_per_s"] = round(d["perms"] / (ms * 1e-3) / 1e9, 3)
+        out[name] = d
+    return out
+
+
 def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=80, provers_per_gpu=3):
     """Map + exchange + Reduce of a MapReduce proof on an already initialised process group: leaf i on rank
     i % world, `provers_per_gpu` concurrent provers per GPU (one ctx = one stream = one host thread each:
@@ -523,6 +559,7 @@ def main():
         r = prove_bench([(20, 80)], quiet=True)[0]
         out["prove"] = {"seconds": r["prove_s_best"], "circuit": r["circuit"], "log_n": 20, "wires": 80, "proof_bytes": r["proof_bytes"],
                         "queries": 28, "pow_bits": 16, "stage_ms": r["stage_ms"],
+                        "stage_detail": prove_stage_detail(r["stage_ms"], 20, 80),
                         "note": "commit wires, Z/partial products, quotient, FRI openings; inputs resident in HBM"}
     if not args.no_prove:
         # ... and the MapReduce shape of CombinedSkip (configs[2]/[3]): 16 leaf proofs per GPU + one all-gather,
