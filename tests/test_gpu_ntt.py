@@ -150,6 +150,33 @@ def test_coset_lde_bitrev_by_cosets(prover, oracle, log_n, rate_bits, batch, shi
         del os.environ["GLP_LDE_PADDED"]
 
 
+def test_full_size_coset_lde_spot_values(prover, pkg):
+    """BASELINE configs[1] size (2^20 coefficients, blow-up 8): sampled outputs of the by-cosets LDE equal
+    f(shift * w_N^bitrev(i)) evaluated from the coefficients by Horner's rule in Python big-ints — a check that
+    does not depend on the oracle's transform and reaches every coset block, including the last element"""
+    rng = np.random.default_rng(2020)
+    log_n, rb, batch = 20, 3, 12
+    n, log_N = 1 << log_n, log_n + rb
+    N = 1 << log_N
+    coeffs = rand_field(rng, (batch, n))
+    coeffs[3, :] = P - 1
+    d_in = prover.to_device(coeffs)
+    d_out = prover.alloc(batch * N * 8)
+    prover.lde_coset_(d_in, d_out, log_n, rb, batch, 7, pkg.NTT_BITREV)
+    w_N = pow(7, (P - 1) >> log_N, P)
+    samples = [(0, 0), (3, N - 1), (batch - 1, N - 1), (batch - 1, n), (5, n - 1)] + \
+              [(int(rng.integers(0, batch)), int(rng.integers(0, N))) for _ in range(19)]
+    for b, i in samples:
+        got = int(d_out.download((1,), offset_bytes=(b * N + i) * 8)[0])
+        x = 7 * pow(w_N, int(format(i, f"0{log_N}b")[::-1], 2), P) % P
+        acc = 0
+        for cf in coeffs[b][::-1].tolist():
+            acc = (acc * x + cf) % P
+        assert got == acc, (b, i)
+    d_in.free()
+    d_out.free()
+
+
 def test_transpose(prover):
     rng = np.random.default_rng(12)
     for rows, cols in ((1, 1), (3, 5), (32, 32), (33, 65), (135, 1024), (1000, 7)):
