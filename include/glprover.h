@@ -17,7 +17,10 @@
  *   - one glp_ctx per GPU per process; a ctx is not thread-safe.  Work is enqueued on the
  *     ctx's HIP stream; functions without an _async suffix return after enqueueing and the
  *     results are ordered on that stream (call glp_sync before reading them on the host).
- *   - there is NO CPU fallback: without a usable gfx950 device glp_create fails.
+ *   - there is NO CPU fallback: without a usable gfx950 device glp_create fails, and nothing the prover
+ *     computes has a host path.  The only host arithmetic in the library is what is host work by nature:
+ *     the Fiat-Shamir transcript (a few hundred permutations with a serial dependency) and the VERIFIERS
+ *     (glp_*_verify*), which a party without a GPU must be able to run.
  */
 #ifndef GLPROVER_H
 #define GLPROVER_H
