@@ -175,12 +175,19 @@ GL_HD u64 gl_reduce128(u64 hi, u64 lo) { return gl_reduce128_t<true>(hi, lo); }
 // 64x64 -> 128 from four 32x32 products chained through v_mad_u64_u32 addends
 template <bool CANON>
 GL_HD u64 gl_mul_t(u64 a, u64 b) {
+#if !defined(__HIP_DEVICE_COMPILE__) && !defined(GLP_EMU) && defined(__SIZEOF_INT128__)
+    // host code of the library (transcript, verifiers): one 64x64 -> 128 multiply; tests/emu keeps the 32-bit-halves
+    // formulation below, which is the one the device compiles
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    return gl_reduce128_t<CANON>((u64)(p >> 64), (u64)p);
+#else
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 p0 = (u64)a0 * b0;
     const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
     const u64 p2 = (u64)a1 * b0 + (u32)p1;
     const u64 p3 = gl_add_u32((u64)a1 * b1 + (p1 >> 32), (u32)(p2 >> 32));   // < 2^64: the product is < 2^128
     return gl_reduce128_t<CANON>(p3, (p2 << 32) | (u32)p0);
+#endif
 }
 GL_HD u64 gl_mul(u64 a, u64 b) { return gl_mul_t<true>(a, b); }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
