@@ -42,6 +42,7 @@ struct glp_ctx {
     std::multimap<size_t, void*> pool_free;      // size -> block
     std::map<void*, size_t> pool_live;           // block -> size
     size_t pool_cached_bytes = 0;
+    size_t pool_cap = 0;                          // resolved on first release (GLP_POOL_CAP_MB or 60 % of device memory)
     // prover stage timers (filled only while profiling is on: each mark synchronises the stream)
     std::vector<std::pair<std::string, float>> stages;
     std::chrono::steady_clock::time_point stage_t0;

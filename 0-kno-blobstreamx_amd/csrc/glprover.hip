@@ -54,9 +54,17 @@ void glp_pool_release(glp_ctx* c, void* p) {
     c->pool_free.emplace(it->second, p);
     c->pool_cached_bytes += it->second;
     c->pool_live.erase(it);
-    const char* cap = getenv("GLP_POOL_CAP_MB");
-    const size_t limit = cap && atoll(cap) > 0 ? (size_t)atoll(cap) << 20 : (size_t)64 << 30;
-    if (c->pool_cached_bytes > limit) glp_pool_trim(c);
+    // cached (released, reusable) blocks may hold up to GLP_POOL_CAP_MB, default 60 % of the device's memory: the
+    // MI355X has 288 GB and a 2^23-row x 80-wire proof recycles ~110 GB of temporaries; with the earlier fixed 64 GiB
+    // cap that size fell into hipFree + hipMalloc of tens of GB per proof (2.9-4.2 s instead of 0.7 s)
+    if (c->pool_cap == 0) {
+        const char* cap = getenv("GLP_POOL_CAP_MB");
+        size_t free_b = 0, total_b = 0;
+        if (cap && atoll(cap) > 0) c->pool_cap = (size_t)atoll(cap) << 20;
+        else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) c->pool_cap = total_b / 10 * 6;
+        else c->pool_cap = (size_t)64 << 30;
+    }
+    if (c->pool_cached_bytes > c->pool_cap) glp_pool_trim(c);
 }
 void glp_pool_trim(glp_ctx* c) {
     if (c->pool_free.empty()) return;
