@@ -198,7 +198,7 @@ def test_argument_errors(prover, pkg):
     d.free()
 
 
-@pytest.mark.parametrize("log_n,batch", [(20, 8), (22, 2), (24, 1)])
+@pytest.mark.parametrize("log_n,batch", [(20, 8), (22, 2), (24, 1), (26, 1), (28, 1)])
 def test_full_size_properties(prover, pkg, log_n, batch):
     """BASELINE sizes (oracle too slow to run many times): round trip, linearity, a delta
     input (-> rows of w^k), and the constant input (-> n at index 0)."""
