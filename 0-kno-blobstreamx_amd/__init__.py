@@ -51,6 +51,35 @@ class FriBatch(ctypes.Structure):
                 ("h_cap", ctypes.c_void_p), ("n_polys", ctypes.c_uint32), ("open_mask", ctypes.c_uint32)]
 
 
+class FriStatement(ctypes.Structure):
+    """what a stand-alone FRI proof proves (glp_fri_statement): the caller compares it with the statement it expects"""
+    _fields_ = [("log_n", ctypes.c_uint32), ("rate_bits", ctypes.c_uint32), ("cap_height", ctypes.c_uint32), ("n_batches", ctypes.c_uint32),
+                ("n_points", ctypes.c_uint32), ("num_queries", ctypes.c_uint32), ("pow_bits", ctypes.c_uint32), ("total_polys", ctypes.c_uint32),
+                ("shift", ctypes.c_uint64), ("zeta", ctypes.c_uint64 * 2), ("point_mult", ctypes.c_uint64 * 4),
+                ("caps_word_off", ctypes.c_size_t), ("cap_words", ctypes.c_size_t), ("openings_word_off", ctypes.c_size_t),
+                ("n_openings", ctypes.c_size_t), ("n_polys", ctypes.c_uint32 * 64), ("open_mask", ctypes.c_uint32 * 64)]
+
+    def as_dict(self, proof):
+        """decoded against the proof bytes: caps [n_batches][cap_words] and openings [(a, b)] in (point, batch, poly) order"""
+        w = np.frombuffer(bytes(proof), dtype="<u8")
+        caps = [[int(v) for v in w[self.caps_word_off + b * self.cap_words: self.caps_word_off + (b + 1) * self.cap_words]]
+                for b in range(self.n_batches)]
+        op = w[self.openings_word_off: self.openings_word_off + 2 * self.n_openings]
+        return {"log_n": self.log_n, "rate_bits": self.rate_bits, "cap_height": self.cap_height, "n_batches": self.n_batches,
+                "n_points": self.n_points, "num_queries": self.num_queries, "pow_bits": self.pow_bits, "shift": self.shift,
+                "zeta": (self.zeta[0], self.zeta[1]), "point_mult": [self.point_mult[i] for i in range(self.n_points)],
+                "n_polys": [self.n_polys[b] for b in range(self.n_batches)], "open_mask": [self.open_mask[b] for b in range(self.n_batches)],
+                "caps": caps, "openings": [(int(op[2 * k]), int(op[2 * k + 1])) for k in range(self.n_openings)]}
+
+
+# security parameters every verify wrapper requires unless the caller says otherwise: 28 queries at rate 1/8 + 16 bits of
+# proof of work (the prover's defaults).  A proof made with weaker parameters is REJECTED by default.
+DEFAULT_MIN_QUERIES = 28
+DEFAULT_MIN_POW_BITS = 16
+DEFAULT_MIN_RATE_BITS = 3
+UNBOUND = "unbound"      # explicit opt-out for plonk_verify*: do not bind the proof to a circuit's verifying key
+
+
 def load_library():
     """dlopen libglprover.so; raises GlpError (never falls back) when it is missing."""
     global _lib
@@ -78,7 +107,10 @@ def load_library():
         "glp_fri_verify": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32]),
         "glp_plonk_verify": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32]),
         "glp_plonk_circuit_cap": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_size_t)]),
-        "glp_tm_merkle_root_var": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, _vp]),
+        "glp_tm_merkle_root_var": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, _vp, ctypes.c_uint64, _vp]),
+        "glp_fri_verify_ex": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp]),
+        "glp_fri_verify_host_ex": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                                  _vp, ctypes.c_char_p, ctypes.c_size_t]),
         "glp_fri_verify_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p,
                                                ctypes.c_size_t]),
         "glp_plonk_verify_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_uint32,
@@ -127,6 +159,7 @@ def load_library():
         "glp_plonk_free": (None, [_vp]),
         "glp_plonk_prove": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp),
                                            ctypes.POINTER(ctypes.c_size_t)]),
+        "glp_plonk_debug_stage": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
     }
     for name, (res, args) in opt.items():
         if hasattr(lib, name):
@@ -157,14 +190,35 @@ def _host_verify(fn_name, constants, proof, extra, min_queries, min_pow_bits):
     raise GlpError(f"{fn_name}: {_ERR.get(rcode, rcode)}")
 
 
-def fri_verify_host(constants, proof, min_queries=1, min_pow_bits=0):
-    """verify a FRI opening proof without a GPU or a ctx; constants = (rc[360], mds_circ[12], mds_diag[12])"""
-    return _host_verify("glp_fri_verify_host", constants, proof, (), min_queries, min_pow_bits)
+def fri_verify_host(constants, proof, min_queries=DEFAULT_MIN_QUERIES, min_pow_bits=DEFAULT_MIN_POW_BITS,
+                    min_rate_bits=DEFAULT_MIN_RATE_BITS, want_statement=False):
+    """verify a FRI opening proof without a GPU or a ctx; constants = (rc[360], mds_circ[12], mds_diag[12]).
+    Returns (accepted, reason) — or (accepted, reason, statement dict) with want_statement: OK alone does not say WHICH
+    statement was proven (log_n, caps, points, openings all come from the proof), compare the statement with yours."""
+    lib = load_library()
+    rc, circ, diag = (np.ascontiguousarray(a, dtype=np.uint64) for a in constants)
+    if rc.size != 360 or circ.size != 12 or diag.size != 12:
+        raise GlpError("Poseidon constants: 360 round constants, 12 + 12 MDS entries")
+    raw = bytes(proof)
+    if len(raw) % 8 or not raw:
+        return (False, "proof length is not a whole number of u64 words") + ((None,) if want_statement else ())
+    words = np.frombuffer(raw, dtype="<u8").copy()
+    err = ctypes.create_string_buffer(256)
+    st = FriStatement()
+    rcode = lib.glp_fri_verify_host_ex(rc.ctypes.data, circ.ctypes.data, diag.ctypes.data, words.ctypes.data, words.nbytes, min_queries,
+                                       min_pow_bits, min_rate_bits, ctypes.addressof(st), err, 256)
+    if rcode not in (0, -7):
+        raise GlpError(f"glp_fri_verify_host_ex: {_ERR.get(rcode, rcode)}")
+    res = (True, None) if rcode == 0 else (False, err.value.decode())
+    return res + ((st.as_dict(raw) if rcode == 0 else None,) if want_statement else ())
 
 
-def plonk_verify_host(constants, proof, circuit_cap=None, min_queries=1, min_pow_bits=0):
-    """verify a circuit proof without a GPU or a ctx; circuit_cap binds it to a circuit (PlonkCircuit.cap())"""
-    cap = None if circuit_cap is None else np.ascontiguousarray(circuit_cap, dtype=np.uint64)
+def plonk_verify_host(constants, proof, circuit_cap, min_queries=DEFAULT_MIN_QUERIES, min_pow_bits=DEFAULT_MIN_POW_BITS):
+    """verify a circuit proof without a GPU or a ctx.  circuit_cap (PlonkCircuit.cap()) binds it to a circuit — required;
+    pass UNBOUND to accept a proof of ANY circuit of that shape (tests, diagnostics)."""
+    if circuit_cap is None:
+        raise GlpError("plonk_verify_host: circuit_cap is required (pass UNBOUND to skip the binding explicitly)")
+    cap = None if isinstance(circuit_cap, str) and circuit_cap == UNBOUND else np.ascontiguousarray(circuit_cap, dtype=np.uint64)
     extra = (cap.ctypes.data if cap is not None else None, cap.size if cap is not None else 0)
     return _host_verify("glp_plonk_verify_host", constants, proof, extra, min_queries, min_pow_bits)
 
@@ -257,6 +311,10 @@ class Prover:
 
     def sync(self):
         self._chk(self.lib.glp_sync(self.ctx), "glp_sync")
+
+    def trim_pool(self):
+        """return the prover drivers' cached temporaries to the driver (glp_trim_pool)"""
+        self._chk(self.lib.glp_trim_pool(self.ctx), "glp_trim_pool")
 
     def set_stream(self, hip_stream):
         self._chk(self.lib.glp_set_stream(self.ctx, hip_stream), "glp_set_stream")
@@ -521,13 +579,21 @@ class Prover:
             return False
         self._chk(rc, what)
 
-    def fri_verify(self, proof, min_queries=1, min_pow_bits=0):
-        """native verifier of a stand-alone FRI opening proof (glp_fri_verify)"""
-        return self._verify("glp_fri_verify", lambda p, n: self.lib.glp_fri_verify(self.ctx, p, n, min_queries, min_pow_bits), proof)
+    def fri_verify(self, proof, min_queries=DEFAULT_MIN_QUERIES, min_pow_bits=DEFAULT_MIN_POW_BITS, min_rate_bits=DEFAULT_MIN_RATE_BITS):
+        """native verifier of a stand-alone FRI opening proof (glp_fri_verify_ex).  On acceptance self.last_statement holds WHAT
+        was proven (log_n, caps, points, openings): the caller must compare it with the statement it expects."""
+        st = FriStatement()
+        ok = self._verify("glp_fri_verify_ex", lambda p, n: self.lib.glp_fri_verify_ex(self.ctx, p, n, min_queries, min_pow_bits,
+                                                                                     min_rate_bits, ctypes.addressof(st)), proof)
+        self.last_statement = st.as_dict(proof) if ok else None
+        return ok
 
-    def plonk_verify(self, proof, circuit_cap=None, min_queries=1, min_pow_bits=0):
-        """native verifier of a PlonkCircuit proof; circuit_cap (PlonkCircuit.cap()) binds it to a circuit"""
-        cap = None if circuit_cap is None else np.ascontiguousarray(circuit_cap, dtype=np.uint64)
+    def plonk_verify(self, proof, circuit_cap, min_queries=DEFAULT_MIN_QUERIES, min_pow_bits=DEFAULT_MIN_POW_BITS):
+        """native verifier of a PlonkCircuit proof; circuit_cap (PlonkCircuit.cap()) binds it to a circuit — required; pass
+        UNBOUND to accept a proof of any circuit of that shape"""
+        if circuit_cap is None:
+            raise GlpError("plonk_verify: circuit_cap is required (pass UNBOUND to skip the binding explicitly)")
+        cap = None if isinstance(circuit_cap, str) and circuit_cap == UNBOUND else np.ascontiguousarray(circuit_cap, dtype=np.uint64)
         return self._verify("glp_plonk_verify",
                             lambda p, n: self.lib.glp_plonk_verify(self.ctx, p, n, cap.ctypes.data if cap is not None else None,
                                                                    cap.size if cap is not None else 0, min_queries, min_pow_bits), proof)
@@ -569,14 +635,14 @@ class Prover:
         n = len(leaves)
         out = ctypes.create_string_buffer(32)
         if n == 0:
-            self._chk(self.lib.glp_tm_merkle_root_var(self.ctx, None, None, 0, out), "glp_tm_merkle_root_var")
+            self._chk(self.lib.glp_tm_merkle_root_var(self.ctx, None, 0, None, 0, out), "glp_tm_merkle_root_var")
             return out.raw
         offs = np.zeros(n + 1, dtype=np.uint64)
         offs[1:] = np.cumsum([len(x) for x in leaves])
         blob = b"".join(leaves) or b"\0"
         d = self.to_device(np.frombuffer(blob, dtype=np.uint8))
         do = self.to_device(offs)
-        self._chk(self.lib.glp_tm_merkle_root_var(self.ctx, d.ptr, do.ptr, n, out), "glp_tm_merkle_root_var")
+        self._chk(self.lib.glp_tm_merkle_root_var(self.ctx, d.ptr, len(blob), do.ptr, n, out), "glp_tm_merkle_root_var")
         d.free()
         do.free()
         return out.raw
@@ -652,6 +718,27 @@ class PlonkCircuit:
         data = ctypes.string_at(proof.value, ln.value)
         self.prover.lib.glp_free_host(proof)
         return data
+
+    def debug_stage(self, wires, which, challenges):
+        """parity hook (glp_plonk_debug_stage): which = "zs" -> [2*M][n] Z / partial products on the trace domain for
+        challenges (beta0, beta1, gamma0, gamma1); which = "quotient" -> [2][8n] quotient evaluations on the LDE coset
+        (bit-reversed order) for (beta0, beta1, gamma0, gamma1, alpha0, alpha1)"""
+        w = np.ascontiguousarray(wires, dtype=np.uint64)
+        n = 1 << self.log_n
+        assert w.shape == (self.n_wires, n)
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64)
+        kind = {"zs": 0, "quotient": 1}[which]
+        assert ch.size == (4 if kind == 0 else 6)
+        shape = (2 * (self.n_wires // 8), n) if kind == 0 else (2, 8 * n)
+        dw = self.prover.to_device(w)
+        do = self.prover.alloc(shape[0] * shape[1] * 8)
+        try:
+            self.prover._chk(self.prover.lib.glp_plonk_debug_stage(self.prover.ctx, self.h, dw.ptr, kind, ch.ctypes.data, do.ptr),
+                             "glp_plonk_debug_stage")
+            return do.download(shape)
+        finally:
+            dw.free()
+            do.free()
 
     def free(self):
         if getattr(self, "h", None):

@@ -301,6 +301,9 @@ __global__ void __launch_bounds__(64) glp_ed25519_witness_kernel(const uint8_t* 
     const uint8_t* sig = sigs + i * 64;
     const uint8_t* msg = msgs + i * (u64)msg_stride;
     const u64 mlen = lens[i];
+    // a length beyond the row stride would read the next signature's message (or past the buffer for the last row):
+    // such a row is INVALID input — record stays all-zero (valid = 0), nothing is hashed
+    if (mlen > msg_stride) return;
     u64 Aenc[4], Renc[4], S[4];
     for (int k = 0; k < 4; k++) { Aenc[k] = glp_load_le64(pub + 8 * k); Renc[k] = glp_load_le64(sig + 8 * k); S[k] = glp_load_le64(sig + 32 + 8 * k); }
     glp_fe Ax, Ay, Rx, Ry;

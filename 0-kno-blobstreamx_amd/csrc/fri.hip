@@ -171,6 +171,7 @@ extern "C" int glp_field_op(glp_ctx* c, int op, const uint64_t* a, const uint64_
 
 int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batch* batches, uint32_t n_batches,
                        glp_challenger& ch, std::vector<u64>& P) {
+    if (!cfg || !batches || n_batches == 0) { glp_set_err(c, "glp_fri_prove: null argument"); return GLP_E_INVALID; }
     const u32 log_n = cfg->log_n, rb = cfg->rate_bits, a = cfg->arity_bits, fb = cfg->final_poly_bits;
     const u32 log_N = log_n + rb;
     if (log_n < 2 || log_n > 26 || rb < 1 || rb > 6 || a < 1 || a > 5 || fb > log_n || cfg->num_queries == 0 || cfg->num_queries > 256 ||
@@ -181,7 +182,6 @@ int glp_fri_prove_impl(glp_ctx* c, const glp_fri_config* cfg, const glp_fri_batc
     const u32 NP = cfg->n_points;
     for (u32 p = 0; p < NP; p++) if (cfg->point_mult[p] == 0 || cfg->point_mult[p] >= GL_P) { glp_set_err(c, "glp_fri_prove: bad point multiplier"); return GLP_E_INVALID; }
     if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set (glp_set_poseidon_constants)"); return GLP_E_STATE; }
-    if (!cfg || !batches || n_batches == 0) { glp_set_err(c, "glp_fri_prove: null argument"); return GLP_E_INVALID; }
     const u64 n = 1ull << log_n, N = 1ull << log_N;
     const u32 cap0 = cfg->cap_height < log_N ? cfg->cap_height : log_N;
     u32 total_polys = 0;

@@ -365,7 +365,12 @@ extern "C" int glp_sync(glp_ctx* c) {
 extern "C" int glp_set_stream(glp_ctx* c, void* s) {
     if (!c) return GLP_E_INVALID;
     GLP_BIND(c);
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    hipStream_t next = s ? (hipStream_t)s : c->own_stream;
+    if (next == c->stream) return GLP_OK;
+    // pool blocks and the NTT scratch are handed out again without waiting because all work of a ctx is ordered on ONE
+    // stream; when that stream changes, drain the old one first or released blocks could be reused under kernels still running
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = next;
     return GLP_OK;
 }
 extern "C" int glp_timer_start(glp_ctx* c) {
@@ -376,6 +381,7 @@ extern "C" int glp_timer_start(glp_ctx* c) {
 }
 extern "C" int glp_timer_stop(glp_ctx* c, float* ms) {
     if (!c || !ms) return GLP_E_INVALID;
+    GLP_BIND(c);
     GLP_HIPCHK(c, hipEventRecord(c->t1, c->stream));
     GLP_HIPCHK(c, hipEventSynchronize(c->t1));
     GLP_HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));

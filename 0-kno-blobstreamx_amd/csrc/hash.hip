@@ -236,10 +236,20 @@ extern "C" int glp_tm_merkle_root(glp_ctx* c, const uint8_t* d_leaves, uint32_t 
     return tm_merkle_root_impl(c, d_leaves, leaf_len, nullptr, n, h_root32);
 }
 // leaves of different lengths: leaf i = d_data[d_offsets[i] .. d_offsets[i+1]) (n + 1 non-decreasing offsets on the device)
-extern "C" int glp_tm_merkle_root_var(glp_ctx* c, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t n, uint8_t* h_root32) {
+extern "C" int glp_tm_merkle_root_var(glp_ctx* c, const uint8_t* d_data, uint64_t data_len, const uint64_t* d_offsets, uint64_t n,
+                                      uint8_t* h_root32) {
     if (!c) return GLP_E_INVALID;
     GLP_BIND(c);
     if (!h_root32 || ((!d_data || !d_offsets) && n) || n > (1ull << 31)) { glp_set_err(c, "glp_tm_merkle_root_var: bad argument"); return GLP_E_INVALID; }
+    if (n) {
+        // the kernel trusts the offsets: check them here (n + 1 words, tiny next to the hashing) — non-decreasing and inside the data
+        std::vector<u64> offs(n + 1);
+        GLP_HIPCHK(c, hipMemcpyAsync(offs.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (u64 i = 0; i < n; i++)
+            if (offs[i] > offs[i + 1]) { glp_set_err(c, "glp_tm_merkle_root_var: offsets decrease at leaf %llu", (unsigned long long)i); return GLP_E_INVALID; }
+        if (offs[n] > data_len) { glp_set_err(c, "glp_tm_merkle_root_var: offsets reach %llu, past data_len %llu", (unsigned long long)offs[n], (unsigned long long)data_len); return GLP_E_INVALID; }
+    }
     return tm_merkle_root_impl(c, d_data, 0, d_offsets, n, h_root32);
 }
 

@@ -111,6 +111,112 @@ extern "C" int glp_plonk_circuit_cap(glp_plonk_circuit* ck, uint64_t* h_cap, siz
     return GLP_OK;
 }
 
+// ---- K6: Z and partial products on the trace domain for given beta, gamma -> zs_vals [NCHAL*M][n] -------
+static int perm_products(glp_ctx* c, glp_plonk_circuit* ck, const u64* d_wire_vals, const u64* beta, const u64* gamma, u64* zs_vals) {
+    const u32 log_n = ck->log_n, W = ck->W, M = W / GLP_PLONK_CHUNK;
+    const u64 n = 1ull << log_n;
+    const u64* wn_lo = nullptr; const u64* wn_hi = nullptr;
+    int rc = glp_ntt_table(c, (int)log_n, 0, &wn_lo, &wn_hi);
+    if (rc) return rc;
+    DBuf qv(c), rr(c), bprod(c);
+    GLP_HIPCHK(c, qv.alloc((size_t)GLP_PLONK_NCHAL * M * n * 8));
+    GLP_HIPCHK(c, rr.alloc((size_t)GLP_PLONK_NCHAL * n * 8));
+    GlpPermArgs pa;
+    pa.wires = d_wire_vals; pa.sigmas = ck->sigma_vals.u(); pa.ks = ck->ks.u(); pa.log_n = log_n; pa.W = W;
+    for (int t = 0; t < GLP_PLONK_NCHAL; t++) { pa.beta[t] = beta[t]; pa.gamma[t] = gamma[t]; }
+    pa.w_lo = wn_lo; pa.w_hi = wn_hi; pa.qv = qv.u(); pa.rr = rr.u();
+    hipLaunchKernelGGL(glp_perm_quotients_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pa);
+    GLP_HIPCHK(c, hipGetLastError());
+    const u32 nb = (u32)((n + GLP_SCAN_BLOCK - 1) / GLP_SCAN_BLOCK);
+    GLP_HIPCHK(c, bprod.alloc((size_t)GLP_PLONK_NCHAL * nb * 8));
+    hipLaunchKernelGGL(glp_scan_reduce_kernel<0>, dim3(nb, GLP_PLONK_NCHAL), dim3(256), 0, c->stream, rr.u(), n, bprod.u());
+    GLP_HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(glp_scan_blocks_kernel<0>, dim3(GLP_PLONK_NCHAL), dim3(GLP_SCAN_TOP), 0, c->stream, bprod.u(), nb);
+    GLP_HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(glp_scan_apply_kernel<0>, dim3(nb, GLP_PLONK_NCHAL), dim3(256), 0, c->stream, rr.u(), qv.u(), n, M, bprod.u(), zs_vals);
+    GLP_HIPCHK(c, hipGetLastError());
+    return GLP_OK;
+}
+
+// ---- K7: quotient evaluations on the LDE domain (bit-reversed order) for given challenges -> quot_rev [NCHAL][N] ----
+static int quotient_evals(glp_ctx* c, glp_plonk_circuit* ck, const u64* wires_lde, const u64* zs_lde, const u64* beta, const u64* gamma,
+                          const u64* alpha, u64* quot_rev) {
+    const u32 log_n = ck->log_n, W = ck->W, rb = ck->rate_bits, M = W / GLP_PLONK_CHUNK;
+    const u32 log_N = log_n + rb;
+    const u64 n = 1ull << log_n, N = 1ull << log_N;
+    const u32 n_con = 1 + 3 * M;
+    std::vector<u64> apow((size_t)GLP_PLONK_NCHAL * n_con);
+    for (int t = 0; t < GLP_PLONK_NCHAL; t++) { u64 x = 1; for (u32 k = 0; k < n_con; k++) { apow[(size_t)t * n_con + k] = x; x = gl_mul(x, alpha[t]); } }
+    DBuf d_apow(c);
+    GLP_HIPCHK(c, d_apow.alloc(apow.size() * 8));
+    GLP_HIPCHK(c, hipMemcpyAsync(d_apow.p, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, c->stream));
+    const u64* wN_lo = nullptr; const u64* wN_hi = nullptr;
+    int rc = glp_ntt_table(c, (int)log_N, 0, &wN_lo, &wN_hi);
+    if (rc) return rc;
+    GlpQuotientArgs qa;
+    qa.consts = ck->pre.lde.u(); qa.sigmas = ck->pre.lde.u() + 3 * N; qa.wires = wires_lde; qa.zs = zs_lde; qa.ks = ck->ks.u();
+    qa.log_n = log_n; qa.rate_bits = rb; qa.W = W;
+    for (int t = 0; t < GLP_PLONK_NCHAL; t++) { qa.beta[t] = beta[t]; qa.gamma[t] = gamma[t]; }
+    qa.alpha_pow = d_apow.u(); qa.w_lo = wN_lo; qa.w_hi = wN_hi; qa.shift = ck->shift;
+    // x^n for natural index e: shift^n * w_N^(e n) = shift^n * w_{2^rb}^(e mod 2^rb)
+    const u64 sn = gl_pow(ck->shift, n), wr = gl_root_of_unity(rb);
+    for (u32 k = 0; k < (1u << rb); k++) qa.zh_inv[k] = gl_inv(gl_sub(gl_mul(sn, gl_pow(wr, k)), 1));
+    qa.n_inv = gl_inv(n % GL_P);
+    qa.inv_xm1 = ck->inv_xm1.u();
+    qa.out = quot_rev;
+    hipLaunchKernelGGL(glp_quotient_kernel<0>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa);
+    GLP_HIPCHK(c, hipGetLastError());
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));      // apow (host) and d_apow die with this frame
+    return GLP_OK;
+}
+
+// values [n_polys][n] (device, consumed) -> coefficients + bit-reversed coset LDE, no Merkle tree (debug stage)
+static int lde_values(glp_ctx* c, u64* d_vals_owned, u32 n_polys, u32 log_n, u32 rb, DBuf& coeffs, DBuf& lde) {
+    coeffs.adopt(d_vals_owned);
+    int rc = glp_ntt(c, coeffs.u(), log_n, n_polys, 1);
+    if (rc) return rc;
+    GLP_HIPCHK(c, lde.alloc(((size_t)n_polys << (log_n + rb)) * 8));
+    return glp_lde_coset(c, coeffs.u(), lde.u(), log_n, rb, n_polys, 7, GLP_NTT_BITREV);
+}
+
+// Parity hook for rows a6 / a7: the prover's intermediate stages for CALLER-CHOSEN challenges, so that the HIP output can be
+// compared with an independent restatement (tests/plonk_ref.py::ref_zs / ref_quotient) instead of only through accepted proofs.
+extern "C" int glp_plonk_debug_stage(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, int which, const uint64_t* h_challenges,
+                                     uint64_t* d_out) {
+    if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
+    if (!ck || !d_wire_vals || !h_challenges || !d_out || (which != GLP_DEBUG_ZS && which != GLP_DEBUG_QUOTIENT)) {
+        glp_set_err(c, "glp_plonk_debug_stage: bad argument");
+        return GLP_E_INVALID;
+    }
+    const u32 n_ch = which == GLP_DEBUG_ZS ? 2 * GLP_PLONK_NCHAL : 3 * GLP_PLONK_NCHAL;
+    for (u32 i = 0; i < n_ch; i++) if (h_challenges[i] >= GL_P) { glp_set_err(c, "glp_plonk_debug_stage: challenge not canonical"); return GLP_E_INVALID; }
+    const u64 *beta = h_challenges, *gamma = h_challenges + GLP_PLONK_NCHAL, *alpha = h_challenges + 2 * GLP_PLONK_NCHAL;
+    const u32 log_n = ck->log_n, W = ck->W, rb = ck->rate_bits, M = W / GLP_PLONK_CHUNK;
+    const u64 n = 1ull << log_n;
+    if (which == GLP_DEBUG_ZS) {
+        int rc = perm_products(c, ck, d_wire_vals, beta, gamma, d_out);
+        if (rc) return rc;
+        GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+        return GLP_OK;
+    }
+    u64* wv = (u64*)glp_pool_alloc(c, (size_t)W * n * 8);
+    if (!wv) return GLP_E_NOMEM;
+    DBuf wco(c), wlde(c), zco(c), zlde(c);
+    GLP_HIPCHK(c, hipMemcpyAsync(wv, d_wire_vals, (size_t)W * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    int rc = lde_values(c, wv, W, log_n, rb, wco, wlde);
+    if (rc) return rc;
+    u64* zv = (u64*)glp_pool_alloc(c, (size_t)GLP_PLONK_NCHAL * M * n * 8);
+    if (!zv) return GLP_E_NOMEM;
+    zco.adopt(zv);
+    rc = perm_products(c, ck, d_wire_vals, beta, gamma, zv);
+    if (rc) return rc;
+    zco.release();
+    rc = lde_values(c, zv, GLP_PLONK_NCHAL * M, log_n, rb, zco, zlde);
+    if (rc) return rc;
+    return quotient_evals(c, ck, wlde.u(), zlde.u(), beta, gamma, alpha, d_out);
+}
+
 extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, uint32_t num_queries, uint32_t pow_bits,
                                uint8_t** proof_out, size_t* proof_len) {
     if (!c) return GLP_E_INVALID;
@@ -153,33 +259,12 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
 
     glp_stage_mark(c, "perm_products(K6)");
     // ---- K6: Z and partial products on the trace domain --------------------------------------
-    const u64* wn_lo = nullptr; const u64* wn_hi = nullptr;
-    int rc = glp_ntt_table(c, (int)log_n, 0, &wn_lo, &wn_hi);
-    if (rc) return rc;
-    DBuf qv(c), rr(c), bprod(c);
-    u64* zs_vals = nullptr;
-    GLP_HIPCHK(c, qv.alloc((size_t)GLP_PLONK_NCHAL * M * n * 8));
-    GLP_HIPCHK(c, rr.alloc((size_t)GLP_PLONK_NCHAL * n * 8));
-    zs_vals = (u64*)glp_pool_alloc(c, (size_t)GLP_PLONK_NCHAL * M * n * 8);
+    u64* zs_vals = (u64*)glp_pool_alloc(c, (size_t)GLP_PLONK_NCHAL * M * n * 8);
     if (!zs_vals) return GLP_E_NOMEM;
     Commit zs(c);
     zs.coeffs.adopt(zs_vals);       // owned from here on (released on any early return)
-    {
-        GlpPermArgs pa;
-        pa.wires = d_wire_vals; pa.sigmas = ck->sigma_vals.u(); pa.ks = ck->ks.u(); pa.log_n = log_n; pa.W = W;
-        for (int t = 0; t < GLP_PLONK_NCHAL; t++) { pa.beta[t] = beta[t]; pa.gamma[t] = gamma[t]; }
-        pa.w_lo = wn_lo; pa.w_hi = wn_hi; pa.qv = qv.u(); pa.rr = rr.u();
-        hipLaunchKernelGGL(glp_perm_quotients_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pa);
-        GLP_HIPCHK(c, hipGetLastError());
-        const u32 nb = (u32)((n + GLP_SCAN_BLOCK - 1) / GLP_SCAN_BLOCK);
-        GLP_HIPCHK(c, bprod.alloc((size_t)GLP_PLONK_NCHAL * nb * 8));
-        hipLaunchKernelGGL(glp_scan_reduce_kernel<0>, dim3(nb, GLP_PLONK_NCHAL), dim3(256), 0, c->stream, rr.u(), n, bprod.u());
-        GLP_HIPCHK(c, hipGetLastError());
-        hipLaunchKernelGGL(glp_scan_blocks_kernel<0>, dim3(GLP_PLONK_NCHAL), dim3(64), 0, c->stream, bprod.u(), nb);
-        GLP_HIPCHK(c, hipGetLastError());
-        hipLaunchKernelGGL(glp_scan_apply_kernel<0>, dim3(nb, GLP_PLONK_NCHAL), dim3(256), 0, c->stream, rr.u(), qv.u(), n, M, bprod.u(), zs_vals);
-        GLP_HIPCHK(c, hipGetLastError());
-    }
+    int rc = perm_products(c, ck, d_wire_vals, beta, gamma, zs_vals);
+    if (rc) return rc;
     zs.coeffs.release();
     glp_stage_mark(c, "commit_zs");
     rc = commit_values(c, zs_vals, GLP_PLONK_NCHAL * M, log_n, rb, ck->cap_h, zs);
@@ -189,31 +274,10 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
 
     glp_stage_mark(c, "quotient(K7)+to_coeffs");
     // ---- K7: quotient on the LDE domain --------------------------------------------------------
-    const u32 n_con = 1 + 3 * M;
-    std::vector<u64> apow((size_t)GLP_PLONK_NCHAL * n_con);
-    for (int t = 0; t < GLP_PLONK_NCHAL; t++) { u64 x = 1; for (u32 k = 0; k < n_con; k++) { apow[(size_t)t * n_con + k] = x; x = gl_mul(x, alpha[t]); } }
-    DBuf d_apow(c), quot_rev(c);
-    GLP_HIPCHK(c, d_apow.alloc(apow.size() * 8));
-    GLP_HIPCHK(c, hipMemcpyAsync(d_apow.p, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, c->stream));
+    DBuf quot_rev(c);
     GLP_HIPCHK(c, quot_rev.alloc((size_t)GLP_PLONK_NCHAL * N * 8));
-    const u64* wN_lo = nullptr; const u64* wN_hi = nullptr;
-    rc = glp_ntt_table(c, (int)log_N, 0, &wN_lo, &wN_hi);
+    rc = quotient_evals(c, ck, wires.lde.u(), zs.lde.u(), beta, gamma, alpha, quot_rev.u());
     if (rc) return rc;
-    {
-        GlpQuotientArgs qa;
-        qa.consts = ck->pre.lde.u(); qa.sigmas = ck->pre.lde.u() + 3 * N; qa.wires = wires.lde.u(); qa.zs = zs.lde.u(); qa.ks = ck->ks.u();
-        qa.log_n = log_n; qa.rate_bits = rb; qa.W = W;
-        for (int t = 0; t < GLP_PLONK_NCHAL; t++) { qa.beta[t] = beta[t]; qa.gamma[t] = gamma[t]; }
-        qa.alpha_pow = d_apow.u(); qa.w_lo = wN_lo; qa.w_hi = wN_hi; qa.shift = ck->shift;
-        // x^n for natural index e: shift^n * w_N^(e n) = shift^n * w_{2^rb}^(e mod 2^rb)
-        const u64 sn = gl_pow(ck->shift, n), wr = gl_root_of_unity(rb);
-        for (u32 k = 0; k < (1u << rb); k++) qa.zh_inv[k] = gl_inv(gl_sub(gl_mul(sn, gl_pow(wr, k)), 1));
-        qa.n_inv = gl_inv(n % GL_P);
-        qa.inv_xm1 = ck->inv_xm1.u();
-        qa.out = quot_rev.u();
-        hipLaunchKernelGGL(glp_quotient_kernel<0>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa);
-        GLP_HIPCHK(c, hipGetLastError());
-    }
     // evaluations (bit-reversed, coset) -> coefficients: un-bit-reverse, inverse NTT, unshift
     u64* quot_nat = (u64*)glp_pool_alloc(c, (size_t)GLP_PLONK_NCHAL * N * 8);
     if (!quot_nat) return GLP_E_NOMEM;

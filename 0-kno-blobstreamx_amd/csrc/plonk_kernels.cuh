@@ -74,9 +74,8 @@ __global__ void __launch_bounds__(256) glp_perm_quotients_kernel(GlpPermArgs a) 
 }
 
 // ---- K6b: exclusive prefix product over rows ------------------------------------------------
-// Three launches: (1) every block reduces its 1024 rows to one product; (2) one block scans
-// the block products (<= 1024 of them per challenge, i.e. n <= 2^20 per launch of this
-// simple form; larger n loops on the host); (3) every block rescans its rows with its prefix.
+// Three launches: (1) every block reduces its 1024 rows to one product; (2) one block per challenge scans
+// the block products; (3) every block rescans its rows with its prefix.
 #define GLP_SCAN_BLOCK 1024u
 template <int UNUSED = 0>
 __global__ void __launch_bounds__(256) glp_scan_reduce_kernel(const u64* __restrict__ rr, u64 n, u64* __restrict__ block_prod) {
@@ -96,13 +95,28 @@ __global__ void __launch_bounds__(256) glp_scan_reduce_kernel(const u64* __restr
     }
     if (threadIdx.x == 0) block_prod[(u64)blockIdx.y * gridDim.x + blockIdx.x] = sh[0];
 }
-// one block per challenge: exclusive scan of nb block products in place (serial over 256-chunks)
+// one block per challenge: exclusive scan of the nb block products in place.  Each work-item owns a contiguous run of
+// ceil(nb / GLP_SCAN_TOP) products (serial inside the run), the run totals are scanned through LDS (Hillis-Steele).
+#define GLP_SCAN_TOP 256u
 template <int UNUSED = 0>
-__global__ void __launch_bounds__(256) glp_scan_blocks_kernel(u64* __restrict__ block_prod, u32 nb) {
-    if (threadIdx.x != 0) return;
+__global__ void __launch_bounds__(GLP_SCAN_TOP) glp_scan_blocks_kernel(u64* __restrict__ block_prod, u32 nb) {
+    __shared__ u64 sh[GLP_SCAN_TOP];
     u64* bp = block_prod + (u64)blockIdx.x * nb;
-    u64 run = 1;
-    for (u32 b = 0; b < nb; b++) { const u64 v = bp[b]; bp[b] = run; run = gl_mul(run, v); }
+    const u32 per = (nb + GLP_SCAN_TOP - 1) / GLP_SCAN_TOP;
+    const u32 b0 = threadIdx.x * per;
+    u64 mine = 1;
+    for (u32 k = 0; k < per; k++) if (b0 + k < nb) mine = gl_mul(mine, bp[b0 + k]);
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (u32 off = 1; off < GLP_SCAN_TOP; off <<= 1) {
+        const u64 add = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 1;
+        __syncthreads();
+        sh[threadIdx.x] = gl_mul(sh[threadIdx.x], add);
+        __syncthreads();
+    }
+    u64 run = threadIdx.x ? sh[threadIdx.x - 1] : 1;
+    for (u32 k = 0; k < per; k++)
+        if (b0 + k < nb) { const u64 v = bp[b0 + k]; bp[b0 + k] = run; run = gl_mul(run, v); }
 }
 // Z[t][i] = prefix(block) * prod_{i' in block, i' < i} rr[t][i'];  each thread handles 4 rows.
 // Also writes the partial products pi_c = Z * q_0..q_c for c < M-1 into zs[t][1+c][i].

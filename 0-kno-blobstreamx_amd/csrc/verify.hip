@@ -102,6 +102,9 @@ bool merkle_check(const Hasher& h, const u64 (&leaf_digest)[4], u64 index, const
 
 struct FriInfo {
     u32 log_n = 0, rb = 0, cap0 = 0, n_pts = 0, nb = 0, nq = 0, pow_bits = 0;
+    u64 shift = 0;
+    u64 mults[4] = {0, 0, 0, 0};
+    size_t caps_off = 0, openings_off = 0;       // word offsets inside the proof
     gl_ext2 zeta{0, 0};
     std::vector<gl_ext2> points;                 // zeta * mult[p]
     std::vector<u64> n_polys, masks;
@@ -113,7 +116,7 @@ struct FriInfo {
 
 // The FRI opening proof starting at rd.pos, continuing the transcript `ch` (fresh for a stand-alone proof).
 int fri_verify(Reject rj, const Hasher& h, glp_challenger& ch, Reader& rd, bool allow_trailing, u32 min_queries, u32 min_pow_bits,
-               FriInfo& fi) {
+               u32 min_rate_bits, FriInfo& fi) {
     const u64* hd;
     if (!rd.take(11, &hd)) return rj.fail("truncated");
     const u64 tag = hd[0], log_n = hd[1], rb = hd[2], cap0 = hd[3], a = hd[4], fb = hd[5], nq = hd[6], pow_bits = hd[7], shift = hd[8],
@@ -123,7 +126,11 @@ int fri_verify(Reject rj, const Hasher& h, glp_challenger& ch, Reader& rd, bool 
     if (log_n > 32 || rb > 8 || log_n + rb > 32 || a == 0 || a > 8 || fb > 12 || nq == 0 || nq > 1024 || pow_bits > 40 || shift == 0 ||
         shift >= GL_P)
         return rj.fail("header out of range");
+    // rate 1 (rate_bits = 0) is no proximity test at all: every word of length n is a codeword of degree < n, so ANY
+    // claimed opening passes.  Never accepted, whatever the caller asks for.
+    if (rb == 0) return rj.fail("rate_bits = 0: a rate-1 code proves nothing");
     if (nq < min_queries || pow_bits < min_pow_bits) return rj.fail("fewer queries or less proof of work than required");
+    if (rb < min_rate_bits) return rj.fail("lower code rate (rate_bits) than required");
     const u64 *mults, *pm;
     if (!rd.take(n_pts, &mults) || !rd.take(2 * nb, &pm)) return rj.fail("truncated");
     bool first_point_used = false;
@@ -144,6 +151,9 @@ int fri_verify(Reject rj, const Hasher& h, glp_challenger& ch, Reader& rd, bool 
     const u32 L = log_n > fb ? (u32)((log_n - fb) / a) : 0;
     const u32 final_bits = (u32)(log_n - a * L);
     fi.log_n = (u32)log_n; fi.rb = (u32)rb; fi.cap0 = (u32)cap0; fi.n_pts = (u32)n_pts; fi.nb = (u32)nb; fi.nq = (u32)nq; fi.pow_bits = (u32)pow_bits;
+    fi.shift = shift;
+    for (u64 p = 0; p < n_pts; p++) fi.mults[p] = mults[p];
+    fi.caps_off = rd.pos;
     for (u64 b = 0; b < nb; b++) {
         const u64* cp;
         if (!rd.take((size_t)4 << cap0, &cp)) return rj.fail("truncated");
@@ -165,6 +175,7 @@ int fri_verify(Reject rj, const Hasher& h, glp_challenger& ch, Reader& rd, bool 
                 total += fi.n_polys[b];
             }
     const u64* op;
+    fi.openings_off = rd.pos;
     if (!rd.take(2 * total, &op)) return rj.fail("truncated");
     fi.openings.resize(total);
     for (size_t k = 0; k < total; k++) {
@@ -381,10 +392,23 @@ gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 W, const std::ve
 static bool proof_args_ok(const uint8_t* proof, size_t len) { return proof && len && len % 8 == 0 && ((uintptr_t)proof & 7) == 0; }
 
 static int fri_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, const uint8_t* proof, size_t len, uint32_t min_queries,
-                            uint32_t min_pow_bits) {
+                            uint32_t min_pow_bits, uint32_t min_rate_bits, glp_fri_statement* st) {
     Reader rd{(const u64*)proof, len / 8, 0};
     FriInfo fi;
-    return fri_verify(rj, h, ch, rd, false, min_queries, min_pow_bits, fi);
+    if (st) memset(st, 0, sizeof(*st));
+    int rc = fri_verify(rj, h, ch, rd, false, min_queries, min_pow_bits, min_rate_bits, fi);
+    if (rc == GLP_OK && st) {     // WHAT was proven: the caller compares it with the statement it expects
+        st->log_n = fi.log_n; st->rate_bits = fi.rb; st->cap_height = fi.cap0; st->n_batches = fi.nb; st->n_points = fi.n_pts;
+        st->num_queries = fi.nq; st->pow_bits = fi.pow_bits; st->shift = fi.shift;
+        st->zeta[0] = fi.zeta.a; st->zeta[1] = fi.zeta.b;
+        for (u32 p = 0; p < 4; p++) st->point_mult[p] = fi.mults[p];
+        st->caps_word_off = fi.caps_off; st->cap_words = (size_t)4 << fi.cap0;
+        st->openings_word_off = fi.openings_off; st->n_openings = fi.openings.size();
+        u32 np = 0;
+        for (u32 b = 0; b < fi.nb && b < 64; b++) { st->n_polys[b] = (u32)fi.n_polys[b]; st->open_mask[b] = (u32)fi.masks[b]; np += (u32)fi.n_polys[b]; }
+        st->total_polys = np;
+    }
+    return rc;
 }
 
 static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, const uint8_t* proof, size_t len, const uint64_t* h_circuit_cap,
@@ -413,7 +437,7 @@ static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, co
     for (u32 t = 0; t < NCHAL; t++) alpha[t] = ch.challenge();
     if (!take_obs(capw, &cap_q)) return rj.fail("truncated");
     FriInfo fi;
-    int rc = fri_verify(rj, h, ch, rd, false, min_queries, min_pow_bits, fi);
+    int rc = fri_verify(rj, h, ch, rd, false, min_queries, min_pow_bits, 1, fi);
     if (rc != GLP_OK) return rc;
     // the FRI part must be about exactly these commitments, shapes and points
     const u64 want_polys[4] = {3 + W, W, (u64)NCHAL * M, (u64)NCHAL << rb};
@@ -456,13 +480,17 @@ static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, co
     return GLP_OK;
 }
 
-extern "C" int glp_fri_verify(glp_ctx* c, const uint8_t* proof, size_t len, uint32_t min_queries, uint32_t min_pow_bits) {
+extern "C" int glp_fri_verify_ex(glp_ctx* c, const uint8_t* proof, size_t len, uint32_t min_queries, uint32_t min_pow_bits,
+                                 uint32_t min_rate_bits, glp_fri_statement* statement) {
     if (!c) return GLP_E_INVALID;
     if (!proof_args_ok(proof, len)) { glp_set_err(c, "glp_fri_verify: bad argument (proof must be 8-byte aligned words)"); return GLP_E_INVALID; }
     Hasher h;
     glp_challenger ch;
     if (!make_hasher(c, h, ch)) return GLP_E_STATE;
-    return fri_verify_entry(Reject{c, nullptr, 0}, h, ch, proof, len, min_queries, min_pow_bits);
+    return fri_verify_entry(Reject{c, nullptr, 0}, h, ch, proof, len, min_queries, min_pow_bits, min_rate_bits, statement);
+}
+extern "C" int glp_fri_verify(glp_ctx* c, const uint8_t* proof, size_t len, uint32_t min_queries, uint32_t min_pow_bits) {
+    return glp_fri_verify_ex(c, proof, len, min_queries, min_pow_bits, 1, nullptr);
 }
 
 extern "C" int glp_plonk_verify(glp_ctx* c, const uint8_t* proof, size_t len, const uint64_t* h_circuit_cap, size_t cap_words,
@@ -477,13 +505,18 @@ extern "C" int glp_plonk_verify(glp_ctx* c, const uint8_t* proof, size_t len, co
 
 // The same verifiers for a host WITHOUT a GPU (a light client, CI): no ctx, the Poseidon constants are passed
 // explicitly (360 + 12 + 12 words, the arguments of glp_set_poseidon_constants); err (may be NULL) receives the reason.
-extern "C" int glp_fri_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* proof, size_t len,
-                                   uint32_t min_queries, uint32_t min_pow_bits, char* err, size_t err_len) {
+extern "C" int glp_fri_verify_host_ex(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* proof,
+                                      size_t len, uint32_t min_queries, uint32_t min_pow_bits, uint32_t min_rate_bits,
+                                      glp_fri_statement* statement, char* err, size_t err_len) {
     if (err && err_len) err[0] = 0;
     Hasher h;
     glp_challenger ch;
     if (!proof_args_ok(proof, len) || !make_hasher_from(h_rc, h_mds_circ, h_mds_diag, h, ch)) return GLP_E_INVALID;
-    return fri_verify_entry(Reject{nullptr, err, err_len}, h, ch, proof, len, min_queries, min_pow_bits);
+    return fri_verify_entry(Reject{nullptr, err, err_len}, h, ch, proof, len, min_queries, min_pow_bits, min_rate_bits, statement);
+}
+extern "C" int glp_fri_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* proof, size_t len,
+                                   uint32_t min_queries, uint32_t min_pow_bits, char* err, size_t err_len) {
+    return glp_fri_verify_host_ex(h_rc, h_mds_circ, h_mds_diag, proof, len, min_queries, min_pow_bits, 1, nullptr, err, err_len);
 }
 extern "C" int glp_plonk_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* proof, size_t len,
                                      const uint64_t* h_circuit_cap, size_t cap_words, uint32_t min_queries, uint32_t min_pow_bits, char* err,

@@ -29,6 +29,11 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# the pass structure the default line runs with; tests/test_gpu_configs.py::test_headline_config_bit_exact checks THIS plan
+# bit for bit against the CPU oracle at the full 128 x 2^20 size, and the line reports whether it ran with it
+EXPECTED_HEADLINE_PLAN = "strip(R=2^10,C=2^3)+finalT(R=2^10,C=2^3)"
+TIMING_PROTOCOL = ("value: wall clock over exactly --steps back-to-back transforms between barrier+synchronize pairs (mean per step, max "
+                   "over ranks); roofline: mean of per-pass HIP-event times over 3-10 profiled transforms; sizes: mean of 10 after 3 warm-ups")
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by profiles/summarize_pmc.py --traffic
 
 
@@ -125,7 +130,7 @@ def cpu_baseline(log_n, seconds_target=15.0):
 
 
 SWEEP = {
-    (20, 128): ["10:3,10:3", "8:4,12:2", "12:2,8:4", "7:5,7:5,6:6", "10:3:5,10:3:5", "10:2:5,10:2:5", "10:4:5,10:4:5", "10:3:5,10:3",
+    (20, 128): ["10:3,10:3", "10:2,10:2", "10:4,10:4", "10:2,10:3", "10:3,10:2", "10:4,10:3", "8:4,12:2", "12:2,8:4", "7:5,7:5,6:6", "10:3:5,10:3:5", "10:2:5,10:2:5", "10:4:5,10:4:5", "10:3:5,10:3",
                 "10:3,10:3:5", "10:4:5,10:3:5", "10:4:5,10:2:5", "9:3:5,11:3", "8:4,8:4,4:6"],
     (22, 32): ["11:3,11:3", "8:4,7:5,7:5", "12:2,10:3", "12:2,10:3:5", "8:4,8:4,6:6", "10:4:5,6:4,6:4", "8:4,7:5,7:5"],
     (24, 8): ["12:2,12:2", "8:4,8:4,8:4", "10:4:5,7:5,7:5", "8:4,8:4,8:5", "9:3:5,9:3:5,6:6", "10:4:5,10:3:5,4:6"],
@@ -284,11 +289,16 @@ def prove_bench(sizes, quiet=False):
             ta = time.perf_counter()
             proof = ck.prove_(dw, 28, 16)
             times.append(time.perf_counter() - ta)
+        # the proof that was timed must be a VALID proof of this circuit: native verifier, bound to the circuit's
+        # verifying key and to the security parameters (host arithmetic, outside the timed region)
+        tv = time.perf_counter()
+        verified = bool(ck.verify(proof, 28, 16))
+        verify_s = time.perf_counter() - tv
         pr.set_profiling(True)                                   # one more proof with stage marks (adds syncs)
         ck.prove_(dw, 28, 16)
         stages = pr.last_stage_ms()
         pr.set_profiling(False)
-        res = {"stage": "plonk_prove", "stage_ms": dict(stages), "circuit": "build-defined arithmetic+permutation circuit (DESIGN.md 3.6), NOT upstream's",
+        res = {"stage": "plonk_prove", "verified": verified, "verify_s": round(verify_s, 4), "stage_ms": dict(stages), "circuit": "build-defined arithmetic+permutation circuit (DESIGN.md 3.6), NOT upstream's",
                "log_n": log_n, "wires": W, "setup_s_incl_h2d": round(t1 - t0, 3), "prove_s": [round(t, 4) for t in times],
                "prove_s_best": round(min(times), 4), "proof_bytes": len(proof), "queries": 28, "pow_bits": 16}
         if not quiet:
@@ -530,7 +540,9 @@ def main():
             "config": {"workload": f"forward NTT, n=2^{log_n}, batch={batch} per GPU, in place, natural order "
                                    f"(BASELINE configs[1] wires shape)", "log_n": log_n, "batch_per_gpu": batch,
                        "plan": pr.describe_plan(log_n, batch), "algorithmic_bytes_per_step": alg_bytes,
-                       "event_ms_per_step": round(ev_ms / args.steps, 4)},
+                       "plan_is_the_bit_exact_tested_plan": (pr.describe_plan(log_n, batch) == EXPECTED_HEADLINE_PLAN
+                                                             if (log_n, batch) == (20, 128) else None),
+                       "event_ms_per_step": round(ev_ms / args.steps, 4), "timing": TIMING_PROTOCOL},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": pmc_traffic_bytes(pr.describe_plan(log_n, batch), float(n) * batch),
@@ -557,7 +569,7 @@ def main():
         # first half of the BASELINE metric, as far as it can be honoured: end-to-end prove time of
         # the build's own 2^20-row circuit (configs[1] size); the upstream circuits are not in the mount
         r = prove_bench([(20, 80)], quiet=True)[0]
-        out["prove"] = {"seconds": r["prove_s_best"], "circuit": r["circuit"], "log_n": 20, "wires": 80, "proof_bytes": r["proof_bytes"],
+        out["prove"] = {"seconds": r["prove_s_best"], "verified": r["verified"], "verify_seconds": r["verify_s"], "circuit": r["circuit"], "log_n": 20, "wires": 80, "proof_bytes": r["proof_bytes"],
                         "queries": 28, "pow_bits": 16, "stage_ms": r["stage_ms"],
                         "stage_detail": prove_stage_detail(r["stage_ms"], 20, 80),
                         "note": "commit wires, Z/partial products, quotient, FRI openings; inputs resident in HBM"}

@@ -62,7 +62,9 @@ int glp_trim_pool(glp_ctx* ctx);
  * current device is per thread, so such a thread calls this once before its first call on the ctx.
  * glp_plonk_setup / glp_plonk_prove / glp_fri_prove bind by themselves. */
 int glp_bind_thread(glp_ctx* ctx);
-/* adopt an external hipStream_t (e.g. torch's current stream); NULL restores the ctx's own */
+/* adopt an external hipStream_t (e.g. torch's current stream); NULL restores the ctx's own.  The ctx's pool and NTT
+ * scratch are reused in stream order, so the switch first WAITS for everything enqueued on the stream being left
+ * (a host-side synchronise): work on the new stream never overlaps work still using those blocks on the old one. */
 int glp_set_stream(glp_ctx* ctx, void* hip_stream);
 /* HIP-event timer on the ctx's stream: start, enqueue work, stop -> elapsed milliseconds */
 int glp_timer_start(glp_ctx* ctx);
@@ -188,6 +190,18 @@ void glp_plonk_free(glp_plonk_circuit* ck);
 int glp_plonk_prove(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, uint32_t num_queries, uint32_t pow_bits,
                     uint8_t** proof, size_t* proof_len);
 
+/* Parity hook for rows a6 / a7: the prover's intermediate stages for CALLER-CHOSEN challenges, so the HIP output can be
+ * compared directly with an independent restatement (tests/plonk_ref.py) and not only through accepted proofs.
+ *   GLP_DEBUG_ZS:       h_challenges = beta[2], gamma[2];           d_out [2*M][n]  Z then the M-1 partial products per
+ *                       challenge, values on the trace domain (M = n_wires / 8)
+ *   GLP_DEBUG_QUOTIENT: h_challenges = beta[2], gamma[2], alpha[2]; d_out [2][8n]   quotient evaluations on the coset
+ *                       7*<w_8n>, bit-reversed index order (before the division into chunks)
+ * Synchronous.  The prover itself never calls it. */
+#define GLP_DEBUG_ZS 0
+#define GLP_DEBUG_QUOTIENT 1
+int glp_plonk_debug_stage(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, int which, const uint64_t* h_challenges,
+                          uint64_t* d_out);
+
 /* the circuit's preprocessed commitment (cap of the constants + sigmas batch) = its verifying key:
  * copies min(*n_words, needed) u64 to h_cap and stores the needed count in *n_words */
 int glp_plonk_circuit_cap(glp_plonk_circuit* ck, uint64_t* h_cap, size_t* n_words);
@@ -200,6 +214,23 @@ int glp_plonk_circuit_cap(glp_plonk_circuit* ck, uint64_t* h_cap, size_t* n_word
  * other codes for bad arguments.  min_queries / min_pow_bits: the security parameters the caller
  * requires (a proof declaring fewer is rejected). */
 int glp_fri_verify(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, uint32_t min_queries, uint32_t min_pow_bits);
+/* A stand-alone FRI proof says "polynomials of degree < 2^log_n behind THESE caps take THESE values at THESE points"; all of that
+ * comes from the proof, so OK/REJECT alone does not tell the caller which statement was proven.  The _ex form also requires a
+ * minimum code rate (rate_bits >= min_rate_bits; rate_bits = 0 is rejected by every entry point: at rate 1 any claimed value
+ * passes) and returns the statement.  The caller MUST compare it with the one it expects (log_n, the caps, the points, the
+ * opened values): caps = words [caps_word_off, + n_batches*cap_words) of the proof, openings = n_openings (a, b) pairs from
+ * openings_word_off in (point, batch, polynomial) order; point p is zeta * point_mult[p], zeta derived from the transcript. */
+typedef struct {
+    uint32_t log_n, rate_bits, cap_height, n_batches, n_points, num_queries, pow_bits, total_polys;
+    uint64_t shift;
+    uint64_t zeta[2];
+    uint64_t point_mult[4];
+    size_t caps_word_off, cap_words;
+    size_t openings_word_off, n_openings;
+    uint32_t n_polys[64], open_mask[64];
+} glp_fri_statement;
+int glp_fri_verify_ex(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, uint32_t min_queries, uint32_t min_pow_bits,
+                      uint32_t min_rate_bits, glp_fri_statement* statement /* may be NULL */);
 /* h_circuit_cap (from glp_plonk_circuit_cap; may be NULL = do not bind to a circuit) */
 int glp_plonk_verify(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, const uint64_t* h_circuit_cap, size_t cap_words,
                      uint32_t min_queries, uint32_t min_pow_bits);
@@ -209,6 +240,9 @@ int glp_plonk_verify(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, con
  * receives the rejection reason.  GLP_E_INVALID for unusable arguments or non-canonical constants. */
 int glp_fri_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
                         size_t proof_len, uint32_t min_queries, uint32_t min_pow_bits, char* err, size_t err_len);
+int glp_fri_verify_host_ex(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
+                           size_t proof_len, uint32_t min_queries, uint32_t min_pow_bits, uint32_t min_rate_bits,
+                           glp_fri_statement* statement, char* err, size_t err_len);
 int glp_plonk_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
                           size_t proof_len, const uint64_t* h_circuit_cap, size_t cap_words, uint32_t min_queries,
                           uint32_t min_pow_bits, char* err, size_t err_len);
@@ -227,7 +261,8 @@ int glp_sha512_trace(glp_ctx* ctx, const uint8_t* d_blocks, uint64_t n_msgs, uin
  * cofactorless check [S]B = R + [k]A.  Per signature GLP_ED25519_RECORD_WORDS u64:
  * [0] valid, [1..4] k = SHA512(R||A||M) mod L, then affine Ax, Ay, Rx, Ry, P1x, P1y (= [S]B),
  * P2x, P2y (= [k]A), each 4 little-endian words.  The message bytes of signature i are
- * d_msgs[i*msg_stride .. + d_lens[i]).  Stream-ordered (glp_sync before reading d_out). */
+ * d_msgs[i*msg_stride .. + d_lens[i]); a row with d_lens[i] > msg_stride is invalid input: its record is all zero
+ * (valid = 0) and nothing is read.  Stream-ordered (glp_sync before reading d_out). */
 #define GLP_ED25519_RECORD_WORDS 37
 int glp_ed25519_witness(glp_ctx* ctx, const uint8_t* d_pubs, const uint8_t* d_sigs, const uint8_t* d_msgs, uint32_t msg_stride,
                         const uint32_t* d_lens, uint64_t n, uint64_t* d_out);
@@ -236,8 +271,10 @@ int glp_ed25519_witness(glp_ctx* ctx, const uint8_t* d_pubs, const uint8_t* d_si
  * the validator-set / header hashing of BASELINE configs[0].  Synchronous; h_root32 = 32 bytes. */
 int glp_tm_merkle_root(glp_ctx* ctx, const uint8_t* d_leaves, uint32_t leaf_len, uint64_t n, uint8_t* h_root32);
 /* the same tree over leaves of different lengths (protobuf-encoded validators, header fields):
- * leaf i = d_data[d_offsets[i] .. d_offsets[i+1]), n + 1 non-decreasing byte offsets (device) */
-int glp_tm_merkle_root_var(glp_ctx* ctx, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t n, uint8_t* h_root32);
+ * leaf i = d_data[d_offsets[i] .. d_offsets[i+1]), n + 1 non-decreasing byte offsets (device), the last one <= data_len
+ * (checked: GLP_E_INVALID otherwise, nothing is read out of range) */
+int glp_tm_merkle_root_var(glp_ctx* ctx, const uint8_t* d_data, uint64_t data_len, const uint64_t* d_offsets, uint64_t n,
+                           uint8_t* h_root32);
 
 /* Multi-GPU (row a11 / SURVEY §8e): leaf subproofs shard one per GPU; the all-gather of the
  * padded proof blobs is done by the host through torch.distributed (RCCL) — see bench.py /

@@ -283,7 +283,7 @@ extern "C" int emu_plonk_zs(const u64* wires, const u64* sigmas, u32 log_n, u32 
     for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
         glp_emu_launch(nb, 256, 0, [&] { blockIdx.y = t; gridDim.y = GLP_PLONK_NCHAL; glp_scan_reduce_kernel<0>(rr.data(), n, bprod.data()); });
     }
-    glp_emu_launch(GLP_PLONK_NCHAL, 64, 0, [&] { glp_scan_blocks_kernel<0>(bprod.data(), nb); });
+    glp_emu_launch(GLP_PLONK_NCHAL, GLP_SCAN_TOP, 0, [&] { glp_scan_blocks_kernel<0>(bprod.data(), nb); });
     for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
         glp_emu_launch(nb, 256, 0, [&] { blockIdx.y = t; gridDim.y = GLP_PLONK_NCHAL; glp_scan_apply_kernel<0>(rr.data(), qv.data(), n, M, bprod.data(), zs); });
     }

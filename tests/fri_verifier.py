@@ -111,7 +111,7 @@ def merkle_check(h, leaf_digest, index, path, cap):
         raise VerifyError("Merkle path does not lead to the cap")
 
 
-def parse_and_verify(proof_bytes, oracle, challenger=None, words=None, pos=0, allow_trailing=False):
+def parse_and_verify(proof_bytes, oracle, challenger=None, words=None, pos=0, allow_trailing=False, min_rate_bits=1):
     """verify a stand-alone FRI proof, or (challenger/words/pos given) the FRI part embedded in a
     larger proof, continuing that proof's transcript"""
     if words is None:
@@ -132,6 +132,10 @@ def parse_and_verify(proof_bytes, oracle, challenger=None, words=None, pos=0, al
         raise VerifyError("bad tag")
     if not (1 <= n_pts <= 4) or nb == 0 or nb > 64:
         raise VerifyError("bad header")
+    # rate 1 proves nothing (every word is a codeword): min_rate_bits=0 exists only so a test can show that a forged
+    # rate-1 proof is otherwise well formed
+    if rb < max(min_rate_bits, 0) or (rb == 0 and min_rate_bits > 0):
+        raise VerifyError("rate_bits below the required minimum (rate 1 proves nothing)")
     mults = take(n_pts)
     pm = take(2 * nb)
     n_polys, masks = pm[0::2], pm[1::2]

@@ -47,6 +47,66 @@ def _worker(rank, world, port, n_leaves, q):
     dist.destroy_process_group()
 
 
+def _golden_leaf_proofs(n_leaves):
+    """real-format leaf proofs for the exchange: the committed golden circuit proof (made by the GPU prover, tests/golden/
+    proofs.json) on the even leaves and a tampered copy (one flipped word) on leaf 3 when it exists"""
+    import json
+    import numpy as np
+    with open(os.path.join(ROOT, "tests", "golden", "proofs.json")) as f:
+        g = json.load(f)["plonk"]
+    good = bytes.fromhex(g["proof"])
+    w = np.frombuffer(good, dtype="<u8").copy()
+    w[len(w) // 2] ^= np.uint64(2)
+    return g, [w.tobytes() if i == 3 else good for i in range(n_leaves)]
+
+
+def _worker_real_proofs(rank, world, port, n_leaves, q):
+    """the Map output is REAL proof bytes: every rank contributes its leaves' proofs, the all-gather reassembles them, and
+    Reduce runs the product's native HOST verifier (no GPU) on the gathered blobs, split across ranks"""
+    import importlib
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as graft
+    from conftest import poseidon_consts
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = graft.load_package()
+    mr = importlib.import_module(graft.PKG_NAME + ".mapreduce")
+    g, blobs = _golden_leaf_proofs(n_leaves)
+    consts = poseidon_consts("small")
+    cap = np.array(g["circuit_cap"], dtype=np.uint64)
+    mine = mr.leaves_of_rank(n_leaves, rank, world)
+    proofs = mr.map_prove_gather(lambda i: blobs[i], n_leaves, padded_len=len(blobs[0]) + 64)
+    ok = proofs == blobs
+    verify = lambda p: pkg.plonk_verify_host(consts, p, cap, g["queries"], g["pow_bits"])[0]
+    verdict_all = mr.reduce_verify(verify, proofs)                         # leaf 3 is tampered (when n_leaves > 3)
+    clean = [blobs[0]] * n_leaves
+    verdict_clean = mr.reduce_verify(verify, clean)
+    q.put((rank, ok, verdict_all, verdict_clean, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_leaves", [6, 3])
+def test_mapreduce_real_proof_blobs_two_ranks(n_leaves):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker_real_proofs, args=(r, world, port, n_leaves, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, verdict_all, verdict_clean, mine in res:
+        assert ok, f"rank {rank}: gathered proofs differ from the leaves' proofs"
+        assert verdict_clean is True, f"rank {rank}: the golden proofs were not accepted"
+        assert verdict_all is (n_leaves <= 3), f"rank {rank}: tampered leaf 3 must flip the verdict on every rank"
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

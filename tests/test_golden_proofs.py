@@ -28,31 +28,111 @@ def test_host_verifier_accepts_golden_and_rejects_tampering(pkg, golden):
     pl, fr = golden["plonk"], golden["fri"]
     proof, cap = bytes.fromhex(pl["proof"]), np.array(pl["circuit_cap"], dtype=np.uint64)
     assert pkg.plonk_verify_host(consts, proof, cap, pl["queries"], pl["pow_bits"]) == (True, None)
-    assert pkg.plonk_verify_host(consts, proof) == (True, None)
+    assert pkg.plonk_verify_host(consts, proof, pkg.UNBOUND, pl["queries"], pl["pow_bits"]) == (True, None)
+    # the wrappers' defaults demand the standard security parameters and a circuit binding: the small golden proof
+    # (8 queries, 4 PoW bits) is refused by default, and omitting the circuit cap is an error, not "accept anything"
+    ok, why = pkg.plonk_verify_host(consts, proof, cap)
+    assert not ok and "fewer queries" in why
+    with pytest.raises(pkg.GlpError):
+        pkg.plonk_verify_host(consts, proof, None)
     ok, why = pkg.plonk_verify_host(consts, proof, cap, pl["queries"] + 1, pl["pow_bits"])
     assert not ok and "fewer queries" in why
     other = cap.copy()
     other[0] ^= np.uint64(1)
-    ok, why = pkg.plonk_verify_host(consts, proof, other)
+    ok, why = pkg.plonk_verify_host(consts, proof, other, pl["queries"], pl["pow_bits"])
     assert not ok and "preprocessed commitment" in why
     words = np.frombuffer(proof, dtype="<u8")
     for t in range(0, len(words), 7):
         bad = words.copy()
         bad[t] ^= np.uint64(1 << (t % 63))
-        assert not pkg.plonk_verify_host(consts, bad.tobytes(), cap)[0], f"word {t}"
-    assert not pkg.plonk_verify_host(consts, proof[:-8], cap)[0] and not pkg.plonk_verify_host(consts, proof + bytes(8), cap)[0]
+        assert not pkg.plonk_verify_host(consts, bad.tobytes(), cap, 1, 0)[0], f"word {t}"
+    assert not pkg.plonk_verify_host(consts, proof[:-8], cap, 1, 0)[0] and not pkg.plonk_verify_host(consts, proof + bytes(8), cap, 1, 0)[0]
     fproof = bytes.fromhex(fr["proof"])
     assert pkg.fri_verify_host(consts, fproof, fr["queries"], fr["pow_bits"]) == (True, None)
+    assert not pkg.fri_verify_host(consts, fproof)[0]                       # defaults: 28 queries / 16 bits required
+    ok, why, st = pkg.fri_verify_host(consts, fproof, fr["queries"], fr["pow_bits"], fr["rate_bits"], want_statement=True)
+    assert ok and (st["log_n"], st["rate_bits"], st["n_polys"], st["num_queries"]) == (fr["log_n"], fr["rate_bits"], fr["polys"], fr["queries"])
+    assert len(st["caps"]) == len(fr["polys"]) and len(st["openings"]) == sum(fr["polys"])
+    ok, why = pkg.fri_verify_host(consts, fproof, fr["queries"], fr["pow_bits"], fr["rate_bits"] + 1)
+    assert not ok and "rate" in why
     fwords = np.frombuffer(fproof, dtype="<u8")
     for t in range(0, len(fwords), 5):
         bad = fwords.copy()
         bad[t] ^= np.uint64(1 << (t % 63))
-        assert not pkg.fri_verify_host(consts, bad.tobytes())[0], f"word {t}"
+        assert not pkg.fri_verify_host(consts, bad.tobytes(), 1, 0, 1)[0], f"word {t}"
     # different constants: the transcript diverges
     big = poseidon_consts("big")
-    assert not pkg.fri_verify_host(big, fproof)[0]
+    assert not pkg.fri_verify_host(big, fproof, 1, 0, 1)[0]
     with pytest.raises(pkg.GlpError):
         pkg.fri_verify_host((consts[0][:100], consts[1], consts[2]), fproof)
+
+
+def forge_rate1_proof(oracle, y=(123456789, 987654321), nq=28):
+    """a 'proof' at rate_bits = 0 for a FALSE opening.  f = one polynomial of 4 coefficients committed on the
+    4-point coset 7<w_4>; the claimed value y != f(zeta).  At rate 1 every word of length 4 is a codeword of degree < 4, so the
+    quotient (f(x) - y)/(x - zeta) on the 4 points always interpolates to a 'final polynomial' and every query passes."""
+    P = fv.P
+    h = fv.Hasher(oracle)
+    ch = fv.Challenger(h)
+    log_n, rb, cap0, a, fb, pw, shift = 2, 0, 0, 1, 2, 0, 7
+    N = 4
+    vals = [11, 22, 33, 44]                                    # f on the domain, bit-reversed order: any 4 values
+    words = [fv.TAG, log_n, rb, cap0, a, fb, nq, pw, shift, 1, 1, 1, 1, 1]        # header, mults [1], (n_polys, mask) = (1, 1)
+    for w in words:
+        ch.observe(w)
+    leaves = [h.hash_or_noop([v]) for v in vals]
+    lvl1 = [h.two_to_one(leaves[0], leaves[1]), h.two_to_one(leaves[2], leaves[3])]
+    root = h.two_to_one(lvl1[0], lvl1[1])
+    words += root
+    for v in root:
+        ch.observe(v)
+    zeta = ch.ext_challenge()
+    words += list(y)
+    for v in y:
+        ch.observe(v)
+    ch.ext_challenge()                                         # alpha: one polynomial, alpha^0 = 1
+    w4 = fv.root(2)
+    xs = [shift * pow(w4, fv.rev(i, 2), P) % P for i in range(N)]
+    G = [fv.emul(fv.esub((vals[i], 0), y), fv.einv(fv.esub((xs[i], 0), zeta))) for i in range(N)]
+    # interpolate G (4 ext values on 4 points): Lagrange, big-int
+    coeffs = [(0, 0)] * N
+    for i in range(N):
+        num = [1]                                              # prod_{j != i} (X - x_j), base-field coefficients
+        den = 1
+        for j in range(N):
+            if j != i:
+                num = [(-xs[j] * (num[k] if k < len(num) else 0) + (num[k - 1] if k else 0)) % P for k in range(len(num) + 1)]
+                den = den * (xs[i] - xs[j]) % P
+        sc = pow(den, P - 2, P)
+        for k in range(N):
+            coeffs[k] = fv.eadd(coeffs[k], fv.escale(G[i], num[k] * sc % P))
+    for cf in coeffs:
+        words += list(cf)
+        for v in cf:
+            ch.observe(v)
+    for _ in range(4):
+        ch.challenge()                                         # PoW seed; pow_bits = 0 accepts any nonce
+    words.append(0)
+    ch.observe(0)
+    idxs = [ch.challenge() & (N - 1) for _ in range(nq)]
+    for idx in idxs:
+        words += [idx, vals[idx]] + leaves[idx ^ 1] + lvl1[(idx >> 1) ^ 1]
+    return np.array(words, dtype=np.uint64).tobytes()
+
+
+def test_forged_rate1_proof_is_rejected(pkg, oracle):
+    """the forged rate-1 proof is well formed in every other respect (the Python verifier accepts it once its rate guard is
+    switched off) and is REJECTED by the native host verifier and by the Python verifier, whatever the caller's minimums"""
+    rc, circ, diag = poseidon_consts("small")
+    oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
+    forged = forge_rate1_proof(oracle)
+    info = fv.parse_and_verify(forged, oracle, min_rate_bits=0)           # guard off: "accepted", which is the attack
+    assert info["rate_bits"] == 0 and info["openings"] == [(123456789, 987654321)]
+    with pytest.raises(fv.VerifyError, match="rate"):
+        fv.parse_and_verify(forged, oracle)
+    for mq, mp, mr in ((28, 0, 0), (1, 0, 0), (28, 0, 1)):
+        ok, why = pkg.fri_verify_host((rc, circ, diag), forged, mq, mp, mr)
+        assert not ok and "rate" in why, (mq, mp, mr, why)
 
 
 def test_python_verifiers_accept_golden(oracle, golden):

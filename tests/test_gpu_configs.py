@@ -1,0 +1,148 @@
+"""The BASELINE.json configurations and the bench headline at FULL size on the GPU, each checked against the CPU oracle
+or an independent verifier (VERDICT r1 "next" item 1):
+
+  (a) the bench's default workload, 128 x 2^20 forward NTT in place with the default plan — and 2^22 x 32, 2^24 x 8 —
+      bit for bit against the hand-reduced CPU transform (oracle/gl_fast.c, itself pinned to the naive oracle and the
+      golden vectors by tests/test_oracle.py);
+  (b) configs[1]: a 2^20-row x 80-wire proof, accepted by the native verifier bound to the circuit's key AND by the
+      independent Python verifier (tests/plonk_ref.py), rejected after one flipped word;
+  (c) configs[2]: MapReduce on one GPU — 3 provers (ctxs) x 16 real 2^16 x 80 leaf proofs, gathered, reduced; one
+      tampered leaf flips the verdict;
+  (e) the 2^23-leaf x 80 Merkle tree that dominates a proof: 64 sampled leaves, their digests and authentication paths
+      up to the cap recomputed by the oracle.
+(d) — direct K6/K7 parity — lives in tests/test_gpu_plonk.py."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import plonk_ref as pref  # noqa: E402
+import fri_verifier as fv  # noqa: E402
+from conftest import P, poseidon_consts, ptr  # noqa: E402
+
+import bench  # noqa: E402  (repo root is on sys.path through conftest)
+import __graft_entry__ as graft  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def setup(prover, oracle):
+    rc, circ, diag = poseidon_consts("small")
+    prover.set_poseidon_constants(rc, circ, diag)
+    oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
+    return prover, oracle
+
+
+@pytest.mark.parametrize("log_n,batch", [(20, 128), (22, 32), (24, 8)])
+def test_headline_config_bit_exact(prover, oracle, log_n, batch):
+    """the exact launch the bench line times (default plan, in place, natural order) vs the CPU oracle, every output word"""
+    import ctypes
+    oracle.orc_set_num_threads.argtypes = [ctypes.c_int]
+    oracle.orc_set_num_threads(bench.effective_cpus())
+    n = 1 << log_n
+    x = bench.splitmix_fill(n * batch, 0x51AB + log_n).reshape(batch, n)
+    plan = prover.describe_plan(log_n, batch)
+    if (log_n, batch) == (20, 128):
+        assert plan == bench.EXPECTED_HEADLINE_PLAN, "the bench's default plan changed: update bench.EXPECTED_HEADLINE_PLAN with it"
+    d = prover.to_device(x)
+    prover.ntt_(d, log_n, batch)
+    got = d.download(x.shape)
+    d.free()
+    oracle.orc_ntt_fast(ptr(x), log_n, batch, 0)          # in place on the host copy
+    assert np.array_equal(got, x), f"{batch} x 2^{log_n} ({plan}) differs from the CPU oracle"
+
+
+def test_configs1_full_size_proof_verifies(setup, pkg):
+    """BASELINE configs[1] size: 2^20 rows x 80 wires, 28 queries, 16 PoW bits (the proof bench.py times)"""
+    prover, oracle = setup
+    consts, sigmas, wires = bench.synthetic_circuit(prover, 20, 80)
+    ck = pkg.PlonkCircuit(prover, consts, sigmas)
+    dw = prover.to_device(wires)
+    proof = ck.prove_(dw, 28, 16)
+    dw.free()
+    assert ck.verify(proof, 28, 16), prover.last_reject                      # native, bound to the circuit cap
+    info = pref.verify_plonk(proof, oracle)                                   # independent Python verifier
+    assert info["log_n"] == 20 and info["W"] == 80
+    words = np.frombuffer(proof, dtype="<u8").copy()
+    for t in (7, len(words) // 3, len(words) - 5):
+        bad = words.copy()
+        bad[t] ^= np.uint64(1)
+        assert not ck.verify(bad.tobytes(), 28, 16), f"native verifier accepted word {t} flipped"
+        with pytest.raises(Exception):
+            pref.verify_plonk(bad.tobytes(), oracle)
+    ck.free()
+    prover.trim_pool()                  # ~20 GB of cached temporaries: give them back before the next test
+
+
+def test_configs2_mapreduce_one_gpu(pkg):
+    """BASELINE configs[2] shape on one GPU: 3 concurrent provers x 16 leaf proofs of 2^16 x 80, one gather, Reduce"""
+    mr = importlib.import_module(graft.PKG_NAME + ".mapreduce")
+    rc, cc, dg = poseidon_consts("small")
+    provers, cks, dws = [], [], []
+    consts = sigmas = wires = None
+    for _ in range(3):
+        pr = pkg.Prover(0)
+        pr.set_poseidon_constants(rc, cc, dg)
+        if consts is None:
+            consts, sigmas, wires = bench.synthetic_circuit(pr, 16, 80)
+        provers.append(pr)
+        cks.append(pkg.PlonkCircuit(pr, consts, sigmas))
+        dws.append(pr.to_device(wires))
+    workers = [(lambda i, c=c, d=d: c.prove_(d, 28, 16)) for c, d in zip(cks, dws)]
+    verifiers = [(lambda p, c=c: c.verify(p, 28, 16)) for c in cks]
+    n_leaves = 16
+    proofs = mr.map_prove_gather(workers, n_leaves, padded_len=1 << 18)
+    assert len(proofs) == n_leaves and all(len(p) > 100_000 for p in proofs)
+    assert mr.reduce_verify(verifiers, proofs) is True
+    assert mr.reduce_verify(verifiers[0], proofs) is True                      # single verifier form
+    bad = list(proofs)
+    w = np.frombuffer(bad[11], dtype="<u8").copy()
+    w[len(w) // 2] ^= np.uint64(4)
+    bad[11] = w.tobytes()
+    assert mr.reduce_verify(verifiers, bad) is False, "a tampered leaf proof did not flip the Reduce verdict"
+    for d, c, q in zip(dws, cks, provers):
+        d.free()
+        c.free()
+        q.close()
+
+
+def test_full_size_merkle_sampled_paths(setup, pkg):
+    """the wires tree of a 2^20-row proof: 2^23 leaves of 80 elements (the bit-reversed coset LDE of 80 random polynomials,
+    hashed straight from the polynomial-major layout), cap height 4.  64 sampled leaves: digest and every node up to the cap
+    recomputed by the oracle from the children the GPU stored"""
+    prover, oracle = setup
+    rng = np.random.default_rng(23)
+    n_polys, log_n, rb, cap_h = 80, 20, 3, 4
+    log_N = log_n + rb
+    N = 1 << log_N
+    co = prover.to_device(bench.splitmix_fill(n_polys << log_n, 99).reshape(n_polys, 1 << log_n))
+    lde = prover.alloc(n_polys * N * 8)
+    prover.lde_coset_(co, lde, log_n, rb, n_polys, 7, pkg.NTT_BITREV)
+    ndig = pkg.Prover.merkle_digest_len(log_N, cap_h)
+    dig = prover.alloc(ndig * 8)
+    cap = prover.merkle_(lde, n_polys, log_N, cap_h, dig, poly_major=True, poly_stride=N)
+    level_base = lambda h: 0 if h == 0 else 4 * (2 * N - (N >> (h - 1)))     # words before level h
+    word = lambda off, k=4: dig.download((k,), offset_bytes=off * 8)
+    idxs = [0, 1, N - 1, N // 2, N // 2 - 1] + [int(v) for v in rng.integers(0, N, 59)]
+    for i in idxs:
+        leaf = np.array([int(lde.download((1,), offset_bytes=(j * N + i) * 8)[0]) for j in range(n_polys)], dtype=np.uint64)
+        cur = np.zeros(4, dtype=np.uint64)
+        oracle.orc_hash_or_noop(ptr(leaf), n_polys, ptr(cur))
+        assert np.array_equal(word(level_base(0) + 4 * i), cur), f"leaf {i}: digest differs from the oracle's"
+        node = i
+        for h in range(log_N - cap_h):
+            sib = word(level_base(h) + 4 * (node ^ 1))
+            out = np.zeros(4, dtype=np.uint64)
+            left, right = (cur, sib) if node % 2 == 0 else (sib, cur)
+            oracle.orc_two_to_one(ptr(np.ascontiguousarray(left)), ptr(np.ascontiguousarray(right)), ptr(out))
+            node >>= 1
+            stored = word(level_base(h + 1) + 4 * node) if h + 1 < log_N - cap_h else cap[node]
+            assert np.array_equal(out, stored), f"leaf {i}: node at level {h + 1} differs from the oracle's"
+            cur = out
+        assert np.array_equal(cur, cap[i >> (log_N - cap_h)])
+    for b in (co, lde, dig):
+        b.free()

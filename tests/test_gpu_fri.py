@@ -80,7 +80,15 @@ def test_prove_then_verify(setup, pkg, oracle, log_n, polys, rb, cap_h, a, fb, n
     proof = prover.fri_prove(list(batches), rb, cap_h, arity_bits=a, final_poly_bits=fb, num_queries=nq, pow_bits=pw)
     info = fv.parse_and_verify(proof, oracle)
     assert info["n_polys"] == polys and len(info["queries"]) == nq
-    assert prover.fri_verify(proof, min_queries=nq, min_pow_bits=pw), prover.last_reject     # native verifier
+    assert prover.fri_verify(proof, min_queries=nq, min_pow_bits=pw, min_rate_bits=rb), prover.last_reject     # native verifier
+    # ... and says WHAT it accepted: the caller binds the proof to its statement by comparing this with what it expects
+    st = prover.last_statement
+    assert (st["log_n"], st["rate_bits"], st["n_polys"], st["num_queries"], st["pow_bits"]) == (log_n, rb, polys, nq, pw)
+    assert st["caps"] == [[int(v) for v in b.cap.reshape(-1)] for b in batches]
+    assert st["zeta"] == info["zeta"] and st["openings"] == info["openings"] and st["point_mult"] == [1]
+    # the defaults demand the prover's standard parameters (28 queries, 16 PoW bits, rate 1/8): weaker proofs are refused
+    assert prover.fri_verify(proof) == (nq >= 28 and pw >= 16 and rb >= 3)
+    assert not prover.fri_verify(proof, nq, pw, min_rate_bits=rb + 1) and "rate" in prover.last_reject
     # the claimed openings are the true evaluations: f(zeta) from the coefficients (oracle ifft)
     zeta = info["zeta"]
     k = 0
@@ -111,6 +119,7 @@ def test_two_opening_points(setup, pkg, oracle):
     proof = prover.fri_prove([b0, b1], rb, cap_h, num_queries=10, pow_bits=6, point_mults=(1, g), open_masks=[1, 3])
     info = fv.parse_and_verify(proof, oracle)
     assert prover.fri_verify(proof, 10, 6), prover.last_reject
+    assert prover.last_statement["point_mult"] == [1, g] and prover.last_statement["open_mask"] == [1, 3]
     assert sorted(info["openings_at"].keys()) == [(0, 0), (0, 1), (1, 1)]
     co = v1.copy()
     oracle.orc_ntt(ptr(co), log_n, 3, 1)
@@ -147,9 +156,9 @@ def test_tampered_proofs_are_rejected(setup, pkg, oracle):
             rejected += 1
         except Exception:
             rejected += 1      # malformed sizes after a header flip count as rejection too
-        assert not prover.fri_verify(bad.tobytes()), f"native verifier accepted a proof with word {t} flipped"
+        assert not prover.fri_verify(bad.tobytes(), 1, 0, 1), f"native verifier accepted a proof with word {t} flipped"
     assert rejected == len(targets)
-    assert prover.fri_verify(proof, 8, 8) and not prover.fri_verify(proof[:-8]) and not prover.fri_verify(proof, 9, 8)
+    assert prover.fri_verify(proof, 8, 8) and not prover.fri_verify(proof[:-8], 8, 8) and not prover.fri_verify(proof, 9, 8)
     with pytest.raises(fv.VerifyError):
         fv.parse_and_verify(proof[:-8], oracle)
     pb.free()

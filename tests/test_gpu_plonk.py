@@ -11,7 +11,7 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fri_verifier as fv  # noqa: E402
 import plonk_ref as pref  # noqa: E402
-from conftest import P, poseidon_consts, ptr  # noqa: E402
+from conftest import P, poseidon_consts, ptr, rand_field  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -36,13 +36,63 @@ def test_prove_and_verify(setup, pkg, log_n, W, nq, pw):
     assert ck.prove(circ["wires"], num_queries=nq, pow_bits=pw) == proof      # deterministic
     # the product's own (native) verifier agrees, bound to this circuit and to the security parameters
     assert ck.verify(proof, min_queries=nq, min_pow_bits=pw), prover.last_reject
-    assert prover.plonk_verify(proof)                                         # unbound
+    assert prover.plonk_verify(proof, pkg.UNBOUND, nq, pw)                    # explicitly unbound
+    assert prover.plonk_verify(proof, ck.cap()) == (nq >= 28 and pw >= 16)    # defaults demand 28 queries / 16 PoW bits
+    with pytest.raises(pkg.GlpError):
+        prover.plonk_verify(proof, None)
     assert not ck.verify(proof, min_queries=nq + 1, min_pow_bits=pw) and "fewer queries" in prover.last_reject
     other = circ["consts"].copy()
     other[1, 0] = (int(other[1, 0]) + 1) % P
     ck2 = pkg.PlonkCircuit(prover, other, circ["sigmas"])                     # a different circuit: different key
-    assert not prover.plonk_verify(proof, ck2.cap()) and "preprocessed commitment" in prover.last_reject
+    assert not prover.plonk_verify(proof, ck2.cap(), nq, pw) and "preprocessed commitment" in prover.last_reject
     ck2.free()
+    ck.free()
+
+
+def _lde_bitrev(oracle, vals, log_n, rb):
+    """values on the trace domain -> coset LDE values, bit-reversed order, by the ORACLE (inverse NTT, pad/scale, NTT)"""
+    co = np.ascontiguousarray(vals).copy()
+    k = co.shape[0]
+    oracle.orc_ntt(ptr(co), log_n, k, 1)
+    out = np.zeros((k, 1 << (log_n + rb)), dtype=np.uint64)
+    oracle.orc_lde_coset(ptr(co), ptr(out), log_n, rb, k, 7)
+    oracle.orc_bitrev_rows(ptr(out), log_n + rb, k)
+    return out
+
+
+@pytest.mark.parametrize("log_n,W", [(6, 8), (8, 16), (10, 24), (12, 8)])
+def test_k6_partial_products_direct_parity(setup, pkg, log_n, W):
+    """row a6 on the GPU, directly: Z and the partial products the HIP kernels compute for caller-chosen (beta, gamma)
+    (glp_plonk_debug_stage) against the by-the-definition Python restatement, every value"""
+    prover, _ = setup
+    rng = np.random.default_rng(1000 * log_n + W)
+    circ = pref.build_circuit(rng, log_n, W)
+    ck = pkg.PlonkCircuit(prover, circ["consts"], circ["sigmas"])
+    beta = [int(v) for v in rand_field(rng, 2)]
+    gamma = [int(v) for v in rand_field(rng, 2)]
+    got = ck.debug_stage(circ["wires"], "zs", beta + gamma)
+    assert np.array_equal(got, pref.ref_zs(circ, beta, gamma))
+    ck.free()
+
+
+@pytest.mark.parametrize("log_n,W", [(6, 8), (8, 16), (10, 8)])
+def test_k7_quotient_direct_parity(setup, pkg, log_n, W):
+    """row a7 on the GPU, directly: the quotient evaluations on the 8n-point coset for caller-chosen challenges against
+    plonk_ref.ref_quotient evaluated on ORACLE-made LDEs of the constants, sigmas, wires and the reference Z's"""
+    prover, oracle = setup
+    rb = 3
+    rng = np.random.default_rng(77 * log_n + W)
+    circ = pref.build_circuit(rng, log_n, W)
+    ck = pkg.PlonkCircuit(prover, circ["consts"], circ["sigmas"])
+    beta = [int(v) for v in rand_field(rng, 2)]
+    gamma = [int(v) for v in rand_field(rng, 2)]
+    alpha = [int(v) for v in rand_field(rng, 2)]
+    got = ck.debug_stage(circ["wires"], "quotient", beta + gamma + alpha)
+    zs = pref.ref_zs(circ, beta, gamma)
+    L = {name: [[int(x) for x in r] for r in _lde_bitrev(oracle, vals, log_n, rb)]
+         for name, vals in (("consts", circ["consts"]), ("sigmas", circ["sigmas"]), ("wires", circ["wires"]), ("zs", zs))}
+    want = pref.ref_quotient(circ, L, beta, gamma, alpha, rb)
+    assert [[int(v) for v in r] for r in got] == want
     ck.free()
 
 
