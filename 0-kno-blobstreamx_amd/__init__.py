@@ -160,6 +160,12 @@ def load_library():
         "glp_plonk_prove": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp),
                                            ctypes.POINTER(ctypes.c_size_t)]),
         "glp_plonk_debug_stage": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
+        "glp_comm_unique_id": (ctypes.c_int, [_vp]),
+        "glp_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+        "glp_comm_rank": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+        "glp_comm_destroy": (ctypes.c_int, [_vp]),
+        "glp_allgather_proofs": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
+        "glp_allreduce_min_u64": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     }
     for name, (res, args) in opt.items():
         if hasattr(lib, name):
@@ -326,6 +332,41 @@ class Prover:
         ms = ctypes.c_float()
         self._chk(self.lib.glp_timer_stop(self.ctx, ctypes.byref(ms)), "glp_timer_stop")
         return ms.value
+
+    # ---- MapReduce exchange behind the C ABI (RCCL communicator owned by the ctx) ------------------------
+    COMM_ID_BYTES = 128
+
+    @staticmethod
+    def comm_unique_id():
+        """rank 0 makes the id; hand its bytes to the other ranks out of band, then every rank calls comm_init"""
+        lib = load_library()
+        buf = ctypes.create_string_buffer(Prover.COMM_ID_BYTES)
+        rc = lib.glp_comm_unique_id(buf)
+        if rc != 0:
+            raise GlpError(f"glp_comm_unique_id: {_ERR.get(rc, rc)}")
+        return buf.raw
+
+    def comm_init(self, comm_id, rank, nranks):
+        assert len(comm_id) == self.COMM_ID_BYTES
+        self._chk(self.lib.glp_comm_init(self.ctx, ctypes.create_string_buffer(bytes(comm_id), self.COMM_ID_BYTES), rank, nranks),
+                  "glp_comm_init")
+        self.comm_rank, self.comm_size = rank, nranks
+
+    def comm_destroy(self):
+        self._chk(self.lib.glp_comm_destroy(self.ctx), "glp_comm_destroy")
+        self.comm_rank = self.comm_size = None
+
+    def allgather_bytes(self, block):
+        """every rank passes a block of the SAME length; returns the nranks blocks concatenated in rank order"""
+        a = np.frombuffer(bytes(block), dtype=np.uint8)
+        out = np.empty(a.size * self.comm_size, dtype=np.uint8)
+        self._chk(self.lib.glp_allgather_proofs(self.ctx, a.ctypes.data, a.size, out.ctypes.data), "glp_allgather_proofs")
+        return out
+
+    def allreduce_min(self, values):
+        v = np.ascontiguousarray(values, dtype=np.uint64).copy()
+        self._chk(self.lib.glp_allreduce_min_u64(self.ctx, v.ctypes.data, v.size), "glp_allreduce_min_u64")
+        return v
 
     FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "mul_pow2": 3, "inv": 4, "reduce128": 5, "reduce128_lazy": 6, "mul_any": 7,
                  "fold_small": 8, "mad_eps_lazy": 9, "mad_eps": 10}

@@ -13,6 +13,7 @@
 
 struct glp_table { u64* lo; u64* hi; };
 struct glp_hash_state;
+struct glp_comm_state;
 
 struct glp_ctx {
     int device = 0;
@@ -36,13 +37,16 @@ struct glp_ctx {
     u64 shift_val = 0;
     int shift_log_n = -1;
     glp_hash_state* hash = nullptr;      // Poseidon constants etc. (hash.hip)
+    glp_comm_state* comm = nullptr;      // RCCL communicator of the MapReduce exchange (comm.hip); null until glp_comm_init
     // device-memory pool for the prover drivers' temporaries: hipMalloc/hipFree cost milliseconds and
     // hipFree synchronises; all work of a ctx is ordered on one stream, so a block released by the host
-    // can be handed to later work of the same stream without waiting (stream-ordered reuse).
+    // can be handed to later work of the same stream without waiting (stream-ordered reuse; glp_set_stream
+    // drains the stream it leaves).  The maps are touched only under the process-wide pool lock (glprover.hip).
     std::multimap<size_t, void*> pool_free;      // size -> block
     std::map<void*, size_t> pool_live;           // block -> size
     size_t pool_cached_bytes = 0;
-    size_t pool_cap = 0;                          // resolved on first release (GLP_POOL_CAP_MB or 60 % of device memory)
+    size_t pool_cap = 0;                          // resolved on first release: GLP_POOL_CAP_MB (per ctx), else 60 % of device memory
+    int pool_cap_env = 0;                         // 0 unresolved, 1 from the environment (per ctx), 2 device share (divided by live ctxs)
     // prover stage timers (filled only while profiling is on: each mark synchronises the stream)
     std::vector<std::pair<std::string, float>> stages;
     std::chrono::steady_clock::time_point stage_t0;
@@ -65,6 +69,8 @@ void glp_set_err(glp_ctx* c, const char* fmt, ...);
 void* glp_pool_alloc(glp_ctx* c, size_t bytes);          // nullptr on failure (error text set)
 void glp_pool_release(glp_ctx* c, void* p);              // back to the pool (no hipFree, no sync)
 void glp_pool_trim(glp_ctx* c);                          // hipFree every cached block
+void glp_pool_register(glp_ctx* c);                      // process-wide registry of live ctxs (shared cap, sibling trim on OOM)
+void glp_pool_unregister(glp_ctx* c);
 
 // RAII block from the ctx pool
 struct GlpPoolBuf {

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/glprover.h"
@@ -23,11 +24,46 @@ void glp_set_err(glp_ctx* c, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------
 // device-memory pool (glp_ctx.h)
 // ---------------------------------------------------------------------------------------
+// Several ctxs may share one GPU (MapReduce map step: K provers per device, one host thread each).  Every pool operation
+// runs under ONE process-wide lock and the live ctxs are registered, so that (a) the cache cap is a share of the device
+// (60 % of its memory divided by the ctxs living on it) instead of 60 % per ctx, and (b) a ctx whose hipMalloc fails can
+// give back its SIBLINGS' cached blocks too, not only its own, before reporting GLP_E_NOMEM.
+static std::mutex g_pool_mu;
+static std::vector<glp_ctx*> g_ctxs;
+void glp_pool_register(glp_ctx* c) { std::lock_guard<std::mutex> lk(g_pool_mu); g_ctxs.push_back(c); }
+void glp_pool_unregister(glp_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_ctxs.size(); i++) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + i); break; }
+}
 static size_t pool_round(size_t bytes) {
     const size_t g = bytes < (1u << 20) ? 4096 : (2u << 20);     // 4 KiB / 2 MiB granules
     return ((bytes ? bytes : 1) + g - 1) / g * g;
 }
+// caller holds g_pool_mu.  The cached blocks of `c` may still be read by kernels enqueued on c's stream: drain it first.
+static void pool_trim_locked(glp_ctx* c) {
+    if (c->pool_free.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pool_free) hipFree(kv.second);
+    c->pool_free.clear();
+    c->pool_cached_bytes = 0;
+}
+static size_t pool_cap_locked(glp_ctx* c) {
+    // cached (released, reusable) blocks may hold up to GLP_POOL_CAP_MB per ctx, default 60 % of the device's memory shared
+    // by the ctxs on that device: the MI355X has 288 GB and a 2^23-row x 80-wire proof recycles ~110 GB of temporaries;
+    // with the earlier fixed 64 GiB cap that size fell into hipFree + hipMalloc of tens of GB per proof (2.9-4.2 s, not 0.7 s)
+    if (c->pool_cap_env == 0) {
+        const char* cap = getenv("GLP_POOL_CAP_MB");
+        size_t free_b = 0, total_b = 0;
+        if (cap && atoll(cap) > 0) { c->pool_cap_env = 1; c->pool_cap = (size_t)atoll(cap) << 20; }
+        else { c->pool_cap_env = 2; c->pool_cap = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) ? total_b / 10 * 6 : ((size_t)64 << 30); }
+    }
+    if (c->pool_cap_env == 1) return c->pool_cap;
+    size_t same = 0;
+    for (glp_ctx* o : g_ctxs) if (o->device == c->device) same++;
+    return c->pool_cap / (same ? same : 1);
+}
 void* glp_pool_alloc(glp_ctx* c, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
     const size_t sz = pool_round(bytes);
     auto it = c->pool_free.lower_bound(sz);
     if (it != c->pool_free.end() && it->first <= sz + sz / 8) {   // reuse a block at most 12.5 % larger
@@ -40,7 +76,11 @@ void* glp_pool_alloc(glp_ctx* c, size_t bytes) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
-        glp_pool_trim(c);                                          // give cached blocks back and retry once
+        pool_trim_locked(c);                                       // give this ctx's cached blocks back and retry ...
+        e = hipMalloc(&p, sz);
+    }
+    if (e != hipSuccess) {
+        for (glp_ctx* o : g_ctxs) if (o != c && o->device == c->device) pool_trim_locked(o);   // ... then the siblings' caches
         e = hipMalloc(&p, sz);
     }
     if (e != hipSuccess) { glp_set_err(c, "device allocation of %zu bytes failed: %s", sz, hipGetErrorString(e)); return nullptr; }
@@ -49,29 +89,17 @@ void* glp_pool_alloc(glp_ctx* c, size_t bytes) {
 }
 void glp_pool_release(glp_ctx* c, void* p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
     auto it = c->pool_live.find(p);
     if (it == c->pool_live.end()) { hipFree(p); return; }          // not ours: plain free
     c->pool_free.emplace(it->second, p);
     c->pool_cached_bytes += it->second;
     c->pool_live.erase(it);
-    // cached (released, reusable) blocks may hold up to GLP_POOL_CAP_MB, default 60 % of the device's memory: the
-    // MI355X has 288 GB and a 2^23-row x 80-wire proof recycles ~110 GB of temporaries; with the earlier fixed 64 GiB
-    // cap that size fell into hipFree + hipMalloc of tens of GB per proof (2.9-4.2 s instead of 0.7 s)
-    if (c->pool_cap == 0) {
-        const char* cap = getenv("GLP_POOL_CAP_MB");
-        size_t free_b = 0, total_b = 0;
-        if (cap && atoll(cap) > 0) c->pool_cap = (size_t)atoll(cap) << 20;
-        else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) c->pool_cap = total_b / 10 * 6;
-        else c->pool_cap = (size_t)64 << 30;
-    }
-    if (c->pool_cached_bytes > c->pool_cap) glp_pool_trim(c);
+    if (c->pool_cached_bytes > pool_cap_locked(c)) pool_trim_locked(c);
 }
 void glp_pool_trim(glp_ctx* c) {
-    if (c->pool_free.empty()) return;
-    hipStreamSynchronize(c->stream);
-    for (auto& kv : c->pool_free) hipFree(kv.second);
-    c->pool_free.clear();
-    c->pool_cached_bytes = 0;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    pool_trim_locked(c);
 }
 extern "C" int glp_trim_pool(glp_ctx* c) {
     if (!c) return GLP_E_INVALID;
@@ -292,6 +320,7 @@ extern "C" int glp_create(glp_ctx** out, int device_id) {
     for (int i = 0; i < 2 * GLP_MAX_PASSES; i++) hipEventCreate(&c->pass_ev[i]);
     const char* cap = getenv("GLP_SCRATCH_CAP_MB");
     c->scratch_cap = (cap && atoll(cap) > 0) ? (size_t)atoll(cap) << 20 : (size_t)4 << 30;
+    glp_pool_register(c);
     *out = c;
     return GLP_OK;
 }
@@ -304,9 +333,11 @@ extern "C" int glp_bind_thread(glp_ctx* c) {
     return GLP_OK;
 }
 
+extern "C" int glp_comm_destroy(glp_ctx* c);
 extern "C" void glp_destroy(glp_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    glp_comm_destroy(c);
     hipStreamSynchronize(c->stream);
     for (auto& kv : c->tables) { if (kv.second.lo) hipFree(kv.second.lo); if (kv.second.hi) hipFree(kv.second.hi); }
     for (auto& kv : c->full_tables) if (kv.second) hipFree(kv.second);
@@ -314,6 +345,7 @@ extern "C" void glp_destroy(glp_ctx* c) {
     if (c->shift_lo) hipFree(c->shift_lo);
     if (c->shift_hi) hipFree(c->shift_hi);
     if (c->scratch) hipFree(c->scratch);
+    glp_pool_unregister(c);
     glp_pool_trim(c);
     for (auto& kv : c->pool_live) hipFree(kv.first);             // blocks a driver still held (error paths)
     c->pool_live.clear();

@@ -40,24 +40,38 @@ def pack_leaves(blobs, padded_len, n_rows=None):
     return torch.from_numpy(out)
 
 
-def allgather_leaf_proofs(local_blobs, n_leaves, padded_len, device=None):
+def _world(comm):
+    """(rank, world): from the prover's own communicator (glp_comm_init) when one is given, else torch.distributed"""
+    if comm is not None:
+        return comm.comm_rank, comm.comm_size
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def allgather_leaf_proofs(local_blobs, n_leaves, padded_len, device=None, comm=None):
     """Every rank passes its own [(leaf_index, proof_bytes)]; returns the list of all
     ``n_leaves`` proofs in leaf order on every rank.  Ranks may own different leaf counts
-    (n_leaves % world != 0): shorter ranks pad with empty records."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    (n_leaves % world != 0): shorter ranks pad with empty records.
+    comm: a Prover whose ctx owns an RCCL communicator (``Prover.comm_init``) — the exchange then runs behind the C ABI
+    (``glp_allgather_proofs``), exactly what a Rust/C++ host would call, instead of through torch.distributed."""
+    _, world = _world(comm)
     per_rank = (n_leaves + world - 1) // world
     if len(local_blobs) > per_rank:
         raise ValueError(f"{len(local_blobs)} local leaves but at most {per_rank} per rank")
     rec = HEADER.size + padded_len
     buf = pack_leaves(local_blobs, padded_len, n_rows=per_rank)
-    if device is not None:
-        buf = buf.to(device)
-    if world > 1:
-        out = torch.empty((world * per_rank, rec), dtype=torch.uint8, device=buf.device)
-        dist.all_gather_into_tensor(out, buf)
+    if comm is not None:
+        rows = comm.allgather_bytes(buf.numpy().tobytes()).reshape(world * per_rank, rec)
     else:
-        out = buf
-    rows = out.cpu().numpy()                      # one d2h copy; slicing below is memcpy, not per-byte Python
+        if device is not None:
+            buf = buf.to(device)
+        if world > 1:
+            out = torch.empty((world * per_rank, rec), dtype=torch.uint8, device=buf.device)
+            dist.all_gather_into_tensor(out, buf)
+        else:
+            out = buf
+        rows = out.cpu().numpy()                  # one d2h copy; slicing below is memcpy, not per-byte Python
     proofs = [None] * n_leaves
     for row in rows:
         idx, ln = HEADER.unpack(row[: HEADER.size].tobytes())
@@ -72,7 +86,7 @@ def allgather_leaf_proofs(local_blobs, n_leaves, padded_len, device=None):
     return proofs
 
 
-def map_prove_gather(prove_leaf, n_leaves, padded_len, device=None):
+def map_prove_gather(prove_leaf, n_leaves, padded_len, device=None, comm=None):
     """The Map + exchange steps of a MapReduce proof: this rank proves leaves
     ``leaves_of_rank(n_leaves, rank, world)`` with ``prove_leaf(i) -> bytes`` — or a LIST of such callables,
     one per concurrent prover of this rank, each run by its own host thread — (e.g.
@@ -80,11 +94,32 @@ def map_prove_gather(prove_leaf, n_leaves, padded_len, device=None):
     proofs in leaf order through ONE all-gather.  The Reduce step upstream is a tree of recursive
     verifier circuits; in this build the gathered proofs are checked by the host-side verifier
     (no in-circuit recursion yet — DESIGN.md §7), so what is returned is the ordered proof list."""
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank, world = _world(comm)
     ids = leaves_of_rank(n_leaves, rank, world)
+    mine, failure = None, None
+    try:
+        mine = _prove_local(prove_leaf, ids)
+    except Exception as e:  # noqa: BLE001 — re-raised below, after every rank knows
+        failure = e
+    # a rank whose map step failed must not leave its peers waiting in the all-gather: agree on success first
+    if world > 1:
+        if comm is not None:
+            everyone_ok = int(comm.allreduce_min([0 if failure is not None else 1])[0])
+        else:
+            flag = torch.tensor([0 if failure is not None else 1], dtype=torch.int32, device=device if device is not None else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            everyone_ok = int(flag.item())
+        if everyone_ok == 0 and failure is None:
+            raise RuntimeError("map step failed on another rank: no leaf proofs were exchanged")
+    if failure is not None:
+        raise failure
+    return allgather_leaf_proofs(mine, n_leaves, padded_len, device=device, comm=comm)
+
+
+def _prove_local(prove_leaf, ids):
+    """this rank's leaf proofs, [(leaf index, bytes)] in leaf order"""
     if callable(prove_leaf):
-        mine = [(i, prove_leaf(i)) for i in ids]
+        return [(i, prove_leaf(i)) for i in ids]
     else:
         # several provers on this GPU (one ctx = one stream each, driven by one host thread each): the
         # launch- and latency-bound phases of one leaf proof (transcript round trips, the top Merkle levels,
@@ -93,19 +128,17 @@ def map_prove_gather(prove_leaf, n_leaves, padded_len, device=None):
         workers = list(prove_leaf)
         with ThreadPoolExecutor(len(workers)) as ex:
             futs = [ex.submit(lambda w=w, sub=ids[k::len(workers)]: [(i, w(i)) for i in sub]) for k, w in enumerate(workers)]
-            mine = sorted((p for f in futs for p in f.result()), key=lambda t: t[0])
-    return allgather_leaf_proofs(mine, n_leaves, padded_len, device=device)
+            return sorted((p for f in futs for p in f.result()), key=lambda t: t[0])
 
 
-def reduce_verify(verify_leaf, proofs, device=None):
+def reduce_verify(verify_leaf, proofs, device=None, comm=None):
     """The Reduce step as far as this build goes: every gathered leaf proof is checked by the native
     verifier (``verify_leaf(proof_bytes) -> bool``, e.g. ``PlonkCircuit.verify``, or a list of them — one per
     ctx — run by one host thread each), the work split across
     ranks — rank r checks the leaves PROVED BY rank r+1 — and the verdicts are combined with one
     all-reduce(MIN).  Upstream folds the leaves with a tree of recursive verifier circuits into one
     proof; here the result is a boolean ("all leaves verify"), not a succinct proof."""
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank, world = _world(comm)
     owner = (rank + 1) % world
     ids = list(range(owner, len(proofs), world))
     if callable(verify_leaf):
@@ -118,7 +151,10 @@ def reduce_verify(verify_leaf, proofs, device=None):
             futs = [ex.submit(lambda v=v, sub=ids[k::len(vs)]: all([v(proofs[i]) for i in sub])) for k, v in enumerate(vs)]
             ok = int(all([f.result() for f in futs]))
     if world > 1:
-        t = torch.tensor([ok], dtype=torch.int32, device=device if device is not None else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        ok = int(t.item())
+        if comm is not None:
+            ok = int(comm.allreduce_min([ok])[0])
+        else:
+            t = torch.tensor([ok], dtype=torch.int32, device=device if device is not None else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
     return bool(ok)

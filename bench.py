@@ -408,6 +408,23 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
     proofs = mr.map_prove_gather(workers, n_leaves, padded_len=1 << 18, device=dev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the same exchange once more behind the C ABI (glp_comm_init / glp_allgather_proofs: the ctx-owned RCCL communicator a
+    # Rust/C++ host would use).  Always at N = 1 (a one-rank communicator cannot wait for anyone); at N > 1 only when asked
+    # (GLP_MAPREDUCE_COMM=abi) until a multi-GPU run of it is on record — torch.distributed stays the default exchange.
+    abi = None
+    if world == 1 or os.environ.get("GLP_MAPREDUCE_COMM") == "abi":
+        try:
+            ids = [pkg.Prover.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            provers[0].comm_init(ids[0], rank, world)
+            mine = [(i, proofs[i]) for i in mr.leaves_of_rank(n_leaves, rank, world)]
+            ta = time.perf_counter()
+            again = mr.allgather_leaf_proofs(mine, n_leaves, 1 << 18, comm=provers[0])
+            abi = {"matches_torch_exchange": again == proofs, "seconds": round(time.perf_counter() - ta, 4), "ranks": world}
+            provers[0].comm_destroy()
+        except Exception as e:  # noqa: BLE001
+            abi = {"error": f"{type(e).__name__}: {e}"[:200]}
     # Reduce as far as this build goes: native verification of every gathered leaf, split across ranks
     t1 = time.perf_counter()
     all_ok = mr.reduce_verify(verifiers, proofs, device=dev)
@@ -419,7 +436,7 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
     res = {"stage": "mapreduce", "n_leaves": n_leaves, "leaves_per_gpu": leaves_per_rank, "leaf_log_n": log_n,
            "leaf_wires": W, "n_gpus": world, "provers_per_gpu": provers_per_gpu, "seconds": round(dt, 4),
            "leaf_proofs_per_s": round(n_leaves / dt, 1), "reduce_verify_seconds": round(dt_red, 4), "all_leaves_verify": all_ok,
-           "leaf_proof_bytes": len(proofs[0]), "all_present": all(len(p) > 0 for p in proofs),
+           "leaf_proof_bytes": len(proofs[0]), "all_present": all(len(p) > 0 for p in proofs), "c_abi_exchange": abi,
            "note": "BASELINE configs[2]/[3] shape with the build-defined leaf circuit (NOT upstream's); seconds = Map + one "
                    "all-gather of padded proofs; Reduce = native verification of every leaf (host arithmetic, split across "
                    "ranks and host threads) + all-reduce of the verdicts, NOT a recursive proof"}

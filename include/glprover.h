@@ -276,9 +276,22 @@ int glp_tm_merkle_root(glp_ctx* ctx, const uint8_t* d_leaves, uint32_t leaf_len,
 int glp_tm_merkle_root_var(glp_ctx* ctx, const uint8_t* d_data, uint64_t data_len, const uint64_t* d_offsets, uint64_t n,
                            uint8_t* h_root32);
 
-/* Multi-GPU (row a11 / SURVEY §8e): leaf subproofs shard one per GPU; the all-gather of the
- * padded proof blobs is done by the host through torch.distributed (RCCL) — see bench.py /
- * INTEGRATION.md — so the C ABI has no communicator entry point. */
+/* ---- Multi-GPU exchange (row a11 / SURVEY §8e, §8(b) glp_allgather_proofs; upstream name recalled: plonky2x mapreduce) ----
+ * Leaf subproofs shard one per GPU, one process (and one ctx) per GPU.  The exchange is ONE RCCL all-gather of fixed-size
+ * blocks over xGMI, on the ctx's stream.  Bootstrap as NCCL does: rank 0 makes the id and hands its GLP_COMM_ID_BYTES bytes
+ * to the other ranks out of band (file, socket, environment, MPI, torch.distributed ...); then EVERY rank calls
+ * glp_comm_init with the same id (collective).  One communicator per ctx; glp_destroy tears it down.
+ * Block format used by the MapReduce host (0-kno-blobstreamx_amd/mapreduce.py::pack_leaves): per leaf a 16-byte header
+ * (u64 leaf index, u64 payload length; index 2^64-1 = unused row) then the proof zero-padded to the agreed length. */
+#define GLP_COMM_ID_BYTES 128
+int glp_comm_unique_id(uint8_t* id_out /* GLP_COMM_ID_BYTES */);
+int glp_comm_init(glp_ctx* ctx, const uint8_t* id /* GLP_COMM_ID_BYTES */, int rank, int nranks);
+int glp_comm_rank(glp_ctx* ctx, int* rank, int* nranks);
+int glp_comm_destroy(glp_ctx* ctx);
+/* every rank passes padded_len bytes (host); h_all receives nranks * padded_len bytes, rank r's block at r * padded_len */
+int glp_allgather_proofs(glp_ctx* ctx, const uint8_t* h_mine, size_t padded_len, uint8_t* h_all);
+/* element-wise minimum over the ranks, in place (the Reduce step's verdicts) */
+int glp_allreduce_min_u64(glp_ctx* ctx, uint64_t* h_io, size_t n);
 
 #ifdef __cplusplus
 }

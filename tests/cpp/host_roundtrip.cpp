@@ -51,6 +51,26 @@ int main() {
     uint64_t nz = 0;
     for (auto v : cap) nz |= v;
     if (!nz) { std::printf("FAIL: empty cap\n"); return 1; }
+    // the MapReduce exchange behind the C ABI (RCCL): a one-rank communicator on this GPU — id, init, all-gather of a padded
+    // block, verdict all-reduce, destroy.  (N > 1 ranks run the same calls, one process per GPU.)
+    {
+        uint8_t id[GLP_COMM_ID_BYTES];
+        CHECK(glp_comm_unique_id(id));
+        if (glp_allgather_proofs(ctx, id, 8, id) != GLP_E_STATE) { std::printf("FAIL: all-gather without a communicator accepted\n"); return 1; }
+        CHECK(glp_comm_init(ctx, id, 0, 1));
+        int rk = -1, nr = -1;
+        CHECK(glp_comm_rank(ctx, &rk, &nr));
+        if (rk != 0 || nr != 1) { std::printf("FAIL: comm rank %d of %d\n", rk, nr); return 1; }
+        std::vector<uint8_t> mine(3 * (16 + 1000)), all(mine.size(), 0xEE);
+        for (size_t i = 0; i < mine.size(); i++) mine[i] = (uint8_t)(splitmix(seed) >> 56);
+        CHECK(glp_allgather_proofs(ctx, mine.data(), mine.size(), all.data()));
+        if (mine != all) { std::printf("FAIL: one-rank all-gather changed the block\n"); return 1; }
+        uint64_t verdict[2] = {1, 7};
+        CHECK(glp_allreduce_min_u64(ctx, verdict, 2));
+        if (verdict[0] != 1 || verdict[1] != 7) { std::printf("FAIL: one-rank all-reduce\n"); return 1; }
+        if (glp_comm_init(ctx, id, 0, 1) != GLP_E_STATE) { std::printf("FAIL: second communicator on one ctx accepted\n"); return 1; }
+        CHECK(glp_comm_destroy(ctx));
+    }
     // error behaviour: bad arguments are reported, not fatal
     if (glp_ntt(ctx, d, 40, 1, 0) != GLP_E_INVALID) { std::printf("FAIL: log_n=40 accepted\n"); return 1; }
     CHECK(glp_free(ctx, d));

@@ -39,6 +39,18 @@ def _worker(rank, world, port, n_leaves, q):
     ok = ok and checked == [fake_proof(i) for i in range((rank + 1) % world, n_leaves, world)]
     bad_leaf = n_leaves - 1
     ok = ok and mr.reduce_verify(lambda p: p != fake_proof(bad_leaf), proofs) is False
+    # a map step that fails on ONE rank must raise on EVERY rank before the all-gather (no peer left waiting in the collective)
+    def flaky(i):
+        if rank == 1:
+            raise ValueError("leaf prover failed")
+        return fake_proof(i)
+    try:
+        mr.map_prove_gather(flaky, n_leaves, padded_len=200)
+        ok = ok and (world == 1 or n_leaves < 2)
+    except ValueError:
+        ok = ok and rank == 1
+    except RuntimeError as e:
+        ok = ok and rank != 1 and "another rank" in str(e)
     # the bench's max-over-ranks time reduction
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -73,3 +73,46 @@ def test_skip_witness(prover, bs):
     assert w["two_thirds_signed"] and w["trusted_power_signed"] == 30 and not w["one_third_of_trusted_signed"] and not w["accept"]
     w = bs.skip_witness(prover, trusted_keys, [11, 10, 10] + [10] * 6, keys, powers, sigs, msgs)
     assert w["trusted_power_signed"] == 31 and w["one_third_of_trusted_signed"] and w["accept"]
+
+
+def test_variable_length_offsets_are_bounded(prover, pkg):
+    """the variable-length leaf kernel trusts its offsets, so the entry point checks them — decreasing offsets
+    or offsets past data_len are GLP_E_INVALID, and nothing is read out of range"""
+    import ctypes
+    data = prover.to_device(np.arange(64, dtype=np.uint8))
+    out = ctypes.create_string_buffer(32)
+    good = prover.to_device(np.array([0, 10, 10, 64], dtype=np.uint64))
+    assert prover.lib.glp_tm_merkle_root_var(prover.ctx, data.ptr, 64, good.ptr, 3, out) == 0
+    assert out.raw == tm_root([bytes(range(0, 10)), b"", bytes(range(10, 64))])
+    for offs, dlen in (([0, 10, 5, 64], 64), ([0, 10, 20, 65], 64), ([0, 10, 20, 2**40], 64), ([0, 10, 20, 64], 63)):
+        bad = prover.to_device(np.array(offs, dtype=np.uint64))
+        assert prover.lib.glp_tm_merkle_root_var(prover.ctx, data.ptr, dlen, bad.ptr, 3, out) == -1, (offs, dlen)
+        bad.free()
+    data.free()
+    good.free()
+
+
+def test_ed25519_overlong_length_is_invalid(prover):
+    """a message length beyond the row stride must not read the neighbour's bytes: the record is all zero"""
+    base = [c for c in load_cases() if c["valid"]][:3]
+    pubs = [bytes.fromhex(c["pub"]) for c in base]
+    sigs = [bytes.fromhex(c["sig"]) for c in base]
+    msgs = [bytes.fromhex(c["msg"]) for c in base]
+    n = len(base)
+    stride = max(1, max(len(m) for m in msgs))
+    P_ = np.frombuffer(b"".join(pubs), dtype=np.uint8).reshape(n, 32)
+    S_ = np.frombuffer(b"".join(sigs), dtype=np.uint8).reshape(n, 64)
+    M_ = np.zeros((n, stride), dtype=np.uint8)
+    for i, m in enumerate(msgs):
+        M_[i, :len(m)] = np.frombuffer(m, dtype=np.uint8)
+    lens = np.array([len(m) for m in msgs], dtype=np.uint32)
+    lens[1] = stride + 1                      # over-long: would read into row 2
+    lens[2] = 0xFFFFFFFF if n > 2 else lens[2]
+    dp, ds, dm, dl = (prover.to_device(a) for a in (P_, S_, M_, lens))
+    do = prover.alloc(n * 37 * 8)
+    prover._chk(prover.lib.glp_ed25519_witness(prover.ctx, dp.ptr, ds.ptr, dm.ptr, stride, dl.ptr, n, do.ptr), "glp_ed25519_witness")
+    rec = do.download((n, 37))
+    assert rec[0, 0] == 1                     # the in-range row still verifies
+    assert not rec[1].any() and not rec[2].any()
+    for b in (dp, ds, dm, dl, do):
+        b.free()

@@ -104,6 +104,13 @@ def test_configs2_mapreduce_one_gpu(pkg):
     w[len(w) // 2] ^= np.uint64(4)
     bad[11] = w.tobytes()
     assert mr.reduce_verify(verifiers, bad) is False, "a tampered leaf proof did not flip the Reduce verdict"
+    # the same exchange and verdict combine behind the C ABI: the ctx-owned RCCL communicator (one rank here)
+    provers[0].comm_init(pkg.Prover.comm_unique_id(), 0, 1)
+    assert mr.allgather_leaf_proofs(list(enumerate(proofs)), n_leaves, 1 << 18, comm=provers[0]) == proofs
+    assert mr.map_prove_gather(workers, 3, padded_len=1 << 18, comm=provers[0]) == proofs[:3]
+    assert mr.reduce_verify(verifiers, proofs, comm=provers[0]) is True and mr.reduce_verify(verifiers, bad, comm=provers[0]) is False
+    assert list(provers[0].allreduce_min([5, 0, 2**63])) == [5, 0, 2**63]
+    provers[0].comm_destroy()
     for d, c, q in zip(dws, cks, provers):
         d.free()
         c.free()
