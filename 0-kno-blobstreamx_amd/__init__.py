@@ -51,6 +51,17 @@ class FriBatch(ctypes.Structure):
                 ("h_cap", ctypes.c_void_p), ("n_polys", ctypes.c_uint32), ("open_mask", ctypes.c_uint32)]
 
 
+class CircuitShape(ctypes.Structure):
+    """glp_circuit_shape"""
+    _fields_ = [("log_n", ctypes.c_uint32), ("n_wires", ctypes.c_uint32), ("n_routed", ctypes.c_uint32), ("n_public", ctypes.c_uint32),
+                ("rate_bits", ctypes.c_uint32), ("cap_height", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
+
+
+PLONK_NCONST = 6                 # constant columns: q_arith, c0, c1, c2, q_pi, q_pos
+CIRCUIT_POSEIDON_GATE = 1
+POS_GATE_WIRES = 130
+
+
 class FriStatement(ctypes.Structure):
     """what a stand-alone FRI proof proves (glp_fri_statement): the caller compares it with the statement it expects"""
     _fields_ = [("log_n", ctypes.c_uint32), ("rate_bits", ctypes.c_uint32), ("cap_height", ctypes.c_uint32), ("n_batches", ctypes.c_uint32),
@@ -159,7 +170,16 @@ def load_library():
         "glp_plonk_free": (None, [_vp]),
         "glp_plonk_prove": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp),
                                            ctypes.POINTER(ctypes.c_size_t)]),
-        "glp_plonk_debug_stage": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
+        "glp_plonk_debug_stage": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
+        "glp_plonk_setup_ex": (ctypes.c_int, [_vp, ctypes.POINTER(CircuitShape), _vp, _vp, ctypes.POINTER(_vp)]),
+        "glp_plonk_prove_ex": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_vp),
+                                              ctypes.POINTER(ctypes.c_size_t)]),
+        "glp_plonk_verify_ex": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_uint32,
+                                               ctypes.c_uint32]),
+        "glp_plonk_verify_host_ex": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]),
+        "glp_plonk_proof_public_inputs": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, ctypes.POINTER(ctypes.c_size_t)]),
+        "glp_poseidon_gate_fill_rows": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint32]),
         "glp_comm_unique_id": (ctypes.c_int, [_vp]),
         "glp_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
         "glp_comm_rank": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
@@ -219,14 +239,39 @@ def fri_verify_host(constants, proof, min_queries=DEFAULT_MIN_QUERIES, min_pow_b
     return res + ((st.as_dict(raw) if rcode == 0 else None,) if want_statement else ())
 
 
-def plonk_verify_host(constants, proof, circuit_cap, min_queries=DEFAULT_MIN_QUERIES, min_pow_bits=DEFAULT_MIN_POW_BITS):
-    """verify a circuit proof without a GPU or a ctx.  circuit_cap (PlonkCircuit.cap()) binds it to a circuit — required;
-    pass UNBOUND to accept a proof of ANY circuit of that shape (tests, diagnostics)."""
+def _public_arg(public):
+    """(pointer-or-None, count, keepalive) for the h_public / n_public pair: None = the statement has NO public inputs (a proof
+    carrying some is rejected), UNBOUND = do not bind, else the expected words"""
+    if isinstance(public, str) and public == UNBOUND:
+        return None, 0, None
+    a = np.ascontiguousarray([] if public is None else [int(v) for v in public], dtype=np.uint64)
+    keep = a if a.size else np.zeros(1, dtype=np.uint64)
+    return keep.ctypes.data, a.size, keep
+
+
+def plonk_verify_host(constants, proof, circuit_cap, min_queries=DEFAULT_MIN_QUERIES, min_pow_bits=DEFAULT_MIN_POW_BITS, public=None):
+    """verify a circuit proof without a GPU or a ctx.  A proof is about (circuit, public inputs): circuit_cap
+    (PlonkCircuit.cap()) binds the circuit — required; public = the expected public inputs (None: the statement has none).
+    Pass UNBOUND for either to skip that binding explicitly (tests, diagnostics)."""
     if circuit_cap is None:
         raise GlpError("plonk_verify_host: circuit_cap is required (pass UNBOUND to skip the binding explicitly)")
     cap = None if isinstance(circuit_cap, str) and circuit_cap == UNBOUND else np.ascontiguousarray(circuit_cap, dtype=np.uint64)
-    extra = (cap.ctypes.data if cap is not None else None, cap.size if cap is not None else 0)
-    return _host_verify("glp_plonk_verify_host", constants, proof, extra, min_queries, min_pow_bits)
+    pp, pn, keep = _public_arg(public)
+    extra = (cap.ctypes.data if cap is not None else None, cap.size if cap is not None else 0, pp, pn)
+    return _host_verify("glp_plonk_verify_host_ex", constants, proof, extra, min_queries, min_pow_bits)
+
+
+def proof_public_inputs(proof):
+    """the public inputs a circuit proof carries (no verification)"""
+    lib = load_library()
+    words = np.frombuffer(bytes(proof), dtype="<u8").copy()
+    n = ctypes.c_size_t(0)
+    if lib.glp_plonk_proof_public_inputs(words.ctypes.data, words.nbytes, None, ctypes.byref(n)) != 0:
+        raise GlpError("not a circuit proof of this format")
+    out = np.zeros(max(1, n.value), dtype=np.uint64)
+    n2 = ctypes.c_size_t(n.value)
+    lib.glp_plonk_proof_public_inputs(words.ctypes.data, words.nbytes, out.ctypes.data, ctypes.byref(n2))
+    return [int(v) for v in out[:n.value]]
 
 
 class DeviceBuffer:
@@ -629,15 +674,30 @@ class Prover:
         self.last_statement = st.as_dict(proof) if ok else None
         return ok
 
-    def plonk_verify(self, proof, circuit_cap, min_queries=DEFAULT_MIN_QUERIES, min_pow_bits=DEFAULT_MIN_POW_BITS):
-        """native verifier of a PlonkCircuit proof; circuit_cap (PlonkCircuit.cap()) binds it to a circuit — required; pass
-        UNBOUND to accept a proof of any circuit of that shape"""
+    def plonk_verify(self, proof, circuit_cap, min_queries=DEFAULT_MIN_QUERIES, min_pow_bits=DEFAULT_MIN_POW_BITS, public=None):
+        """native verifier of a PlonkCircuit proof.  A proof is about (circuit, public inputs): circuit_cap (PlonkCircuit.cap())
+        binds the circuit — required; public = the expected public inputs (None: the statement has none).  UNBOUND for either
+        skips that binding explicitly."""
         if circuit_cap is None:
             raise GlpError("plonk_verify: circuit_cap is required (pass UNBOUND to skip the binding explicitly)")
         cap = None if isinstance(circuit_cap, str) and circuit_cap == UNBOUND else np.ascontiguousarray(circuit_cap, dtype=np.uint64)
-        return self._verify("glp_plonk_verify",
-                            lambda p, n: self.lib.glp_plonk_verify(self.ctx, p, n, cap.ctypes.data if cap is not None else None,
-                                                                   cap.size if cap is not None else 0, min_queries, min_pow_bits), proof)
+        pp, pn, keep = _public_arg(public)
+        return self._verify("glp_plonk_verify_ex",
+                            lambda p, n: self.lib.glp_plonk_verify_ex(self.ctx, p, n, cap.ctypes.data if cap is not None else None,
+                                                                      cap.size if cap is not None else 0, pp, pn, min_queries, min_pow_bits),
+                            proof)
+
+    def poseidon_gate_fill_rows(self, d_wires, log_n, n_wires, rows):
+        """witness generation for Poseidon rows: wires 12..129 of every listed row from its wires 0..11, in place on the device"""
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        if r.size == 0:
+            return
+        dr = self.to_device(r)
+        try:
+            self._chk(self.lib.glp_poseidon_gate_fill_rows(self.ctx, _ptr(d_wires), log_n, n_wires, dr.ptr, r.size), "glp_poseidon_gate_fill_rows")
+            self.sync()
+        finally:
+            dr.free()
 
     def ed25519_witness(self, pubs, sigs, msgs):
         """pubs/sigs/msgs: lists of bytes.  Returns [n][37] u64 records (glprover.h)."""
@@ -712,24 +772,34 @@ def sha_pad(msg: bytes, block: int, blocks: int = None) -> bytes:
 
 
 class PlonkCircuit:
-    """Preprocessed build-defined circuit (glp_plonk_setup): constants (q, c0, c1) and sigma
-    columns committed once; prove(wires) returns the proof bytes.  DESIGN.md §3.6."""
+    """Preprocessed build-defined circuit (glp_plonk_setup_ex): constant columns and sigma columns committed once;
+    prove(wires, public) returns the proof bytes.  DESIGN.md §3.6.
+      consts: [6][n] = (q_arith, c0, c1, c2, q_pi, q_pos) row values — or the round-1 form [3][n] = (q, c0, c1)
+      sigmas: [n_routed][n];  n_wires: total wire columns (default: all routed);  n_public: rows 0..n_public-1 expose wire 0
+      poseidon: q_pos rows carry a permutation (needs n_wires >= 130, n_routed >= 24)"""
 
-    def __init__(self, prover, consts, sigmas, rate_bits=3, cap_height=4):
+    def __init__(self, prover, consts, sigmas, rate_bits=3, cap_height=4, n_wires=None, n_public=0, poseidon=False):
         self.prover = prover
         c = np.ascontiguousarray(consts, dtype=np.uint64)
         s = np.ascontiguousarray(sigmas, dtype=np.uint64)
-        self.n_wires, n = s.shape
+        self.n_routed, n = s.shape
+        self.n_wires = self.n_routed if n_wires is None else int(n_wires)
+        self.n_public = int(n_public)
+        self.flags = CIRCUIT_POSEIDON_GATE if poseidon else 0
         self.log_n = n.bit_length() - 1
-        assert c.shape == (3, n) and 1 << self.log_n == n
+        assert 1 << self.log_n == n and c.shape in ((3, n), (PLONK_NCONST, n))
+        if c.shape[0] == 3:
+            c = np.concatenate([c, np.zeros((3, n), dtype=np.uint64)])
         dc, ds = prover.to_device(c), prover.to_device(s)
         h = _vp()
-        prover._chk(prover.lib.glp_plonk_setup(prover.ctx, self.log_n, self.n_wires, dc.ptr, ds.ptr, rate_bits, cap_height,
-                                               ctypes.byref(h)), "glp_plonk_setup")
+        shape = CircuitShape(self.log_n, self.n_wires, self.n_routed, self.n_public, rate_bits, cap_height, self.flags)
+        try:
+            prover._chk(prover.lib.glp_plonk_setup_ex(prover.ctx, ctypes.byref(shape), dc.ptr, ds.ptr, ctypes.byref(h)), "glp_plonk_setup_ex")
+        finally:
+            dc.free()
+            ds.free()
         self.h = h
         prover._circuits.append(self)
-        dc.free()
-        ds.free()
 
     def cap(self):
         """the preprocessed commitment (constants + sigmas): the circuit's verifying key"""
@@ -739,28 +809,38 @@ class PlonkCircuit:
         self.prover._chk(self.prover.lib.glp_plonk_circuit_cap(self.h, out.ctypes.data, ctypes.byref(n)), "glp_plonk_circuit_cap")
         return out
 
-    def verify(self, proof, min_queries=28, min_pow_bits=16):
-        return self.prover.plonk_verify(proof, self.cap(), min_queries, min_pow_bits)
+    def verify(self, proof, min_queries=28, min_pow_bits=16, public=None):
+        """bound to this circuit and to the statement `public` (None: no public inputs; UNBOUND: any)"""
+        if public is None and self.n_public:
+            raise GlpError("verify: this circuit has public inputs — pass the expected ones (or UNBOUND)")
+        return self.prover.plonk_verify(proof, self.cap(), min_queries, min_pow_bits, public=public)
 
-    def prove(self, wires, num_queries=28, pow_bits=16):
+    def _public_words(self, public):
+        pub = np.ascontiguousarray([] if public is None else [int(v) for v in public], dtype=np.uint64)
+        if pub.size != self.n_public:
+            raise GlpError(f"{pub.size} public inputs given, the circuit has {self.n_public}")
+        return pub if pub.size else None
+
+    def prove(self, wires, num_queries=28, pow_bits=16, public=None):
         w = np.ascontiguousarray(wires, dtype=np.uint64)
         assert w.shape == (self.n_wires, 1 << self.log_n)
         dw = self.prover.to_device(w)
         try:
-            return self.prove_(dw, num_queries, pow_bits)
+            return self.prove_(dw, num_queries, pow_bits, public=public)
         finally:
             dw.free()
 
-    def prove_(self, d_wires, num_queries=28, pow_bits=16):
+    def prove_(self, d_wires, num_queries=28, pow_bits=16, public=None):
         proof = _vp()
         ln = ctypes.c_size_t()
-        self.prover._chk(self.prover.lib.glp_plonk_prove(self.prover.ctx, self.h, _ptr(d_wires), num_queries, pow_bits,
-                                                         ctypes.byref(proof), ctypes.byref(ln)), "glp_plonk_prove")
+        pub = self._public_words(public)
+        self.prover._chk(self.prover.lib.glp_plonk_prove_ex(self.prover.ctx, self.h, _ptr(d_wires), pub.ctypes.data if pub is not None else None,
+                                                            num_queries, pow_bits, ctypes.byref(proof), ctypes.byref(ln)), "glp_plonk_prove_ex")
         data = ctypes.string_at(proof.value, ln.value)
         self.prover.lib.glp_free_host(proof)
         return data
 
-    def debug_stage(self, wires, which, challenges):
+    def debug_stage(self, wires, which, challenges, public=None):
         """parity hook (glp_plonk_debug_stage): which = "zs" -> [2*M][n] Z / partial products on the trace domain for
         challenges (beta0, beta1, gamma0, gamma1); which = "quotient" -> [2][8n] quotient evaluations on the LDE coset
         (bit-reversed order) for (beta0, beta1, gamma0, gamma1, alpha0, alpha1)"""
@@ -770,12 +850,13 @@ class PlonkCircuit:
         ch = np.ascontiguousarray(challenges, dtype=np.uint64)
         kind = {"zs": 0, "quotient": 1}[which]
         assert ch.size == (4 if kind == 0 else 6)
-        shape = (2 * (self.n_wires // 8), n) if kind == 0 else (2, 8 * n)
+        shape = (2 * (self.n_routed // 8), n) if kind == 0 else (2, 8 * n)
+        pub = self._public_words(public)
         dw = self.prover.to_device(w)
         do = self.prover.alloc(shape[0] * shape[1] * 8)
         try:
-            self.prover._chk(self.prover.lib.glp_plonk_debug_stage(self.prover.ctx, self.h, dw.ptr, kind, ch.ctypes.data, do.ptr),
-                             "glp_plonk_debug_stage")
+            self.prover._chk(self.prover.lib.glp_plonk_debug_stage(self.prover.ctx, self.h, dw.ptr, pub.ctypes.data if pub is not None else None,
+                                                                   kind, ch.ctypes.data, do.ptr), "glp_plonk_debug_stage")
             return do.download(shape)
         finally:
             dw.free()

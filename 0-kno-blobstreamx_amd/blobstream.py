@@ -157,3 +157,12 @@ def unpack_skip_inputs(b: bytes):
     if len(b) != 48:
         raise ValueError("skip inputs are 48 bytes")
     return struct.unpack(">Q", b[:8])[0], b[8:40], struct.unpack(">Q", b[40:])[0]
+
+
+def public_words(packed: bytes):
+    """the packed public values as field elements for the circuit's public-input rows: big-endian 32-bit words, one per element
+    (each < 2^32 < p, so the map bytes -> elements is injective).  BUILD-DEFINED: how plonky2x maps evm_read/evm_write bytes to
+    public-input targets is not in the mount ([RECALLED]: one target per byte); the verifier only needs both sides to agree."""
+    if len(packed) % 4:
+        raise ValueError("public values must be a whole number of 32-bit words")
+    return [int.from_bytes(packed[i:i + 4], "big") for i in range(0, len(packed), 4)]

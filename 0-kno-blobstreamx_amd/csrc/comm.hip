@@ -8,12 +8,52 @@
 // the exchange is one ncclAllGather of bytes on the ctx's stream (ordered with the prover's work on that stream).
 // Host buffers in and out (the proofs are host objects: the transcript and the serialisation run on the host); the
 // staging blocks come from the ctx pool.
+//
+// RCCL is bound at FIRST USE (dlopen of librccl.so.1), not at link time: a process that never calls glp_comm_* never loads it,
+// and a host that already carries an RCCL (e.g. PyTorch's bundled one) shares that instance instead of getting a second
+// runtime in the process.  (Linked directly, loading this library before PyTorch left PyTorch unable to see the GPU.)
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <string.h>
+#include <mutex>
 #include "glp_ctx.h"
 
 static_assert(sizeof(ncclUniqueId) == GLP_COMM_ID_BYTES, "glprover.h's GLP_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+
+namespace {
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    char why[256] = {0};
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+const Rccl& rccl() {
+    std::call_once(g_rccl_once, [] {
+        void* h = nullptr;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        if (!h) { snprintf(g_rccl.why, sizeof(g_rccl.why), "cannot load librccl: %s", dlerror()); return; }
+        bool all = true;
+        auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) { all = false; snprintf(g_rccl.why, sizeof(g_rccl.why), "librccl lacks %s", n); } return p; };
+        g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+        g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+        g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+        g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+        g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+        g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+        g_rccl.ok = all;
+    });
+    return g_rccl;
+}
+}  // namespace
+#define ncclGetErrorString rccl().GetErrorString
 
 struct glp_comm_state {
     ncclComm_t comm = nullptr;
@@ -31,8 +71,9 @@ struct glp_comm_state {
 
 extern "C" int glp_comm_unique_id(uint8_t* id_out) {
     if (!id_out) return GLP_E_INVALID;
+    if (!rccl().ok) return GLP_E_UNSUPPORTED;
     ncclUniqueId id;
-    if (ncclGetUniqueId(&id) != ncclSuccess) return GLP_E_HIP;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return GLP_E_HIP;
     memcpy(id_out, &id, sizeof(id));
     return GLP_OK;
 }
@@ -42,10 +83,11 @@ extern "C" int glp_comm_init(glp_ctx* c, const uint8_t* id_in, int rank, int nra
     GLP_BIND(c);
     if (!id_in || nranks < 1 || rank < 0 || rank >= nranks) { glp_set_err(c, "glp_comm_init: bad argument"); return GLP_E_INVALID; }
     if (c->comm) { glp_set_err(c, "glp_comm_init: this ctx already has a communicator (glp_comm_destroy first)"); return GLP_E_STATE; }
+    if (!rccl().ok) { glp_set_err(c, "glp_comm_init: %s", rccl().why); return GLP_E_UNSUPPORTED; }
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof(id));
     glp_comm_state* st = new glp_comm_state();
-    ncclResult_t r = ncclCommInitRank(&st->comm, nranks, id, rank);     // collective: every rank calls it with the same id
+    ncclResult_t r = rccl().CommInitRank(&st->comm, nranks, id, rank);     // collective: every rank calls it with the same id
     if (r != ncclSuccess) { delete st; glp_set_err(c, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, ncclGetErrorString(r)); return GLP_E_HIP; }
     st->rank = rank; st->nranks = nranks;
     c->comm = st;
@@ -64,7 +106,7 @@ extern "C" int glp_comm_destroy(glp_ctx* c) {
     if (!c->comm) return GLP_OK;
     GLP_BIND(c);
     hipStreamSynchronize(c->stream);
-    ncclCommDestroy(c->comm->comm);
+    rccl().CommDestroy(c->comm->comm);
     delete c->comm;
     c->comm = nullptr;
     return GLP_OK;
@@ -82,7 +124,7 @@ extern "C" int glp_allgather_proofs(glp_ctx* c, const uint8_t* h_mine, size_t pa
     GLP_HIPCHK(c, d_in.alloc(padded_len));
     GLP_HIPCHK(c, d_out.alloc(padded_len * nr));
     GLP_HIPCHK(c, hipMemcpyAsync(d_in.p, h_mine, padded_len, hipMemcpyHostToDevice, c->stream));
-    GLP_NCCLCHK(c, ncclAllGather(d_in.p, d_out.p, padded_len, ncclUint8, c->comm->comm, c->stream));
+    GLP_NCCLCHK(c, rccl().AllGather(d_in.p, d_out.p, padded_len, ncclUint8, c->comm->comm, c->stream));
     GLP_HIPCHK(c, hipMemcpyAsync(h_all, d_out.p, padded_len * nr, hipMemcpyDeviceToHost, c->stream));
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     return GLP_OK;
@@ -97,7 +139,7 @@ extern "C" int glp_allreduce_min_u64(glp_ctx* c, uint64_t* h_io, size_t n) {
     GlpPoolBuf d(c);
     GLP_HIPCHK(c, d.alloc(n * 8));
     GLP_HIPCHK(c, hipMemcpyAsync(d.p, h_io, n * 8, hipMemcpyHostToDevice, c->stream));
-    GLP_NCCLCHK(c, ncclAllReduce(d.p, d.p, n, ncclUint64, ncclMin, c->comm->comm, c->stream));
+    GLP_NCCLCHK(c, rccl().AllReduce(d.p, d.p, n, ncclUint64, ncclMin, c->comm->comm, c->stream));
     GLP_HIPCHK(c, hipMemcpyAsync(h_io, d.p, n * 8, hipMemcpyDeviceToHost, c->stream));
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     return GLP_OK;

@@ -2,8 +2,9 @@
 // a6, a7 and the prover skeleton around them; upstream name recalled, unverified:
 // plonky2::plonk::prover::prove — reference file:line NONE, the mount is empty).
 //
-//   setup : constants (q, c0, c1) and sigma columns -> ifft -> coset LDE -> Merkle  (batch 0)
-//   prove : wires -> batch 1 ; beta, gamma x2 ; Z + partial products (K6) -> batch 2 ;
+//   setup : constant columns (plonk_gates.h) and sigma columns -> ifft -> coset LDE -> Merkle  (batch 0)
+//   prove : header + public inputs + preprocessed cap into the transcript ; wires -> batch 1 ; beta, gamma x2 ;
+//           Z + partial products over the routed wires (K6) -> batch 2 ;
 //           alpha x2 ; quotient on the LDE domain (K7) -> coefficients -> 8 chunks -> batch 3 ;
 //           FRI opening proof of all four batches at zeta, and of batch 2 at g*zeta.
 // Everything proportional to n runs in kernels; the host runs the transcript and sequencing.
@@ -33,9 +34,9 @@ struct Commit {                 // one PolynomialBatch kept on the device
 }  // namespace
 
 struct glp_plonk_circuit {       // must be freed (glp_plonk_free) before its ctx is destroyed
-    u32 log_n, W, rate_bits, cap_h;
+    u32 log_n, W, R, n_public, flags, rate_bits, cap_h;
     u64 shift;
-    DBuf sigma_vals;            // [W][n] values on the trace domain (K6 input)
+    DBuf sigma_vals;            // [R][n] values on the trace domain (K6 input)
     DBuf ks, inv_xm1;
     std::vector<u64> h_ks;
     Commit pre;                 // constants + sigmas
@@ -59,34 +60,44 @@ static int commit_values(glp_ctx* c, u64* d_vals_owned, u32 n_polys, u32 log_n, 
     return glp_merkle_from_polys(c, out.lde.u(), N, n_polys, log_N, ch, out.dig.u(), out.cap.data());
 }
 
-extern "C" int glp_plonk_setup(glp_ctx* c, uint32_t log_n, uint32_t n_wires, const uint64_t* d_const_vals, const uint64_t* d_sigma_vals,
-                               uint32_t rate_bits, uint32_t cap_height, glp_plonk_circuit** out) {
+extern "C" int glp_plonk_setup_ex(glp_ctx* c, const glp_circuit_shape* sh, const uint64_t* d_const_vals, const uint64_t* d_sigma_vals,
+                                  glp_plonk_circuit** out) {
     if (!c) return GLP_E_INVALID;
     GLP_BIND(c);
-    if (!out || !d_const_vals || !d_sigma_vals || log_n < 3 || log_n > 24 || n_wires == 0 || n_wires % 8 || n_wires > 128 || rate_bits != 3 ||
-        cap_height > 12) {
-        glp_set_err(c, "glp_plonk_setup: unsupported shape (W %% 8 == 0, W <= 128, rate_bits == 3)");
+    if (!out || !sh || !d_const_vals || !d_sigma_vals) { glp_set_err(c, "glp_plonk_setup: null argument"); return GLP_E_INVALID; }
+    const u32 log_n = sh->log_n, n_wires = sh->n_wires, R = sh->n_routed;
+    // rate_bits is structural, not a tunable: the permutation constraint has degree 9 (Z times eight linear factors) and a
+    // Poseidon row degree 8, so the quotient has degree < 8n — 8 chunks, evaluated on the 8n-point coset; a larger blow-up
+    // would only make every commitment bigger.  W <= 160 = 20 chunks of wires: what the K7 register budget was sized for.
+    if (log_n < 3 || log_n > 24 || n_wires == 0 || n_wires % 8 || n_wires > 160 || R == 0 || R % 8 || R > n_wires || sh->rate_bits != 3 ||
+        sh->cap_height > 12 || sh->n_public > (1u << log_n) || (sh->flags & ~GLP_CIRCUIT_POSEIDON_GATE)) {
+        glp_set_err(c, "glp_plonk_setup: unsupported shape (W %% 8 == 0, W <= 160, routed %% 8 == 0, routed <= W, rate_bits == 3, n_public <= n)");
+        return GLP_E_INVALID;
+    }
+    if ((sh->flags & GLP_CIRCUIT_POSEIDON_GATE) && (n_wires < GLP_POS_GATE_WIRES || R < 24)) {
+        glp_set_err(c, "glp_plonk_setup: a Poseidon-gate circuit needs >= %d wires, >= 24 of them routed", GLP_POS_GATE_WIRES);
         return GLP_E_INVALID;
     }
     if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set"); return GLP_E_STATE; }
     std::unique_ptr<glp_plonk_circuit> ck(new glp_plonk_circuit(c));
-    ck->log_n = log_n; ck->W = n_wires; ck->rate_bits = rate_bits; ck->cap_h = cap_height; ck->shift = 7;
+    ck->log_n = log_n; ck->W = n_wires; ck->R = R; ck->n_public = sh->n_public; ck->flags = sh->flags;
+    ck->rate_bits = sh->rate_bits; ck->cap_h = sh->cap_height; ck->shift = 7;
     const u64 n = 1ull << log_n;
-    const u32 log_N = log_n + rate_bits;
+    const u32 log_N = log_n + ck->rate_bits;
     const u64 N = 1ull << log_N;
     // coset representatives k_j = 7^j
-    ck->h_ks.resize(n_wires);
-    { u64 t = 1; for (u32 j = 0; j < n_wires; j++) { ck->h_ks[j] = t; t = gl_mul(t, 7); } }
-    GLP_HIPCHK(c, ck->ks.alloc(n_wires * 8));
-    GLP_HIPCHK(c, hipMemcpyAsync(ck->ks.p, ck->h_ks.data(), n_wires * 8, hipMemcpyHostToDevice, c->stream));
-    GLP_HIPCHK(c, ck->sigma_vals.alloc((size_t)n_wires * n * 8));
-    GLP_HIPCHK(c, hipMemcpyAsync(ck->sigma_vals.p, d_sigma_vals, (size_t)n_wires * n * 8, hipMemcpyDeviceToDevice, c->stream));
-    // batch 0 = [q, c0, c1, sigma_0 .. sigma_{W-1}]
-    u64* pre_vals = (u64*)glp_pool_alloc(c, (size_t)(3 + n_wires) * n * 8);
+    ck->h_ks.resize(R);
+    { u64 t = 1; for (u32 j = 0; j < R; j++) { ck->h_ks[j] = t; t = gl_mul(t, 7); } }
+    GLP_HIPCHK(c, ck->ks.alloc(R * 8));
+    GLP_HIPCHK(c, hipMemcpyAsync(ck->ks.p, ck->h_ks.data(), R * 8, hipMemcpyHostToDevice, c->stream));
+    GLP_HIPCHK(c, ck->sigma_vals.alloc((size_t)R * n * 8));
+    GLP_HIPCHK(c, hipMemcpyAsync(ck->sigma_vals.p, d_sigma_vals, (size_t)R * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    // batch 0 = [the GLP_PLONK_NCONST constant columns, sigma_0 .. sigma_{R-1}]
+    u64* pre_vals = (u64*)glp_pool_alloc(c, (size_t)(GLP_PLONK_NCONST + R) * n * 8);
     if (!pre_vals) return GLP_E_NOMEM;
-    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals, d_const_vals, (size_t)3 * n * 8, hipMemcpyDeviceToDevice, c->stream));
-    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals + 3 * n, d_sigma_vals, (size_t)n_wires * n * 8, hipMemcpyDeviceToDevice, c->stream));
-    int rc = commit_values(c, pre_vals, 3 + n_wires, log_n, rate_bits, cap_height, ck->pre);
+    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals, d_const_vals, (size_t)GLP_PLONK_NCONST * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals + GLP_PLONK_NCONST * n, d_sigma_vals, (size_t)R * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    int rc = commit_values(c, pre_vals, GLP_PLONK_NCONST + R, log_n, ck->rate_bits, ck->cap_h, ck->pre);
     if (rc) return rc;
     // 1 / (x - 1) on the LDE domain
     const u64* w_lo = nullptr; const u64* w_hi = nullptr;
@@ -101,7 +112,38 @@ extern "C" int glp_plonk_setup(glp_ctx* c, uint32_t log_n, uint32_t n_wires, con
     return GLP_OK;
 }
 
+// the round-1 entry point: every wire routed, no public inputs, constants (q, c0, c1) -> (q, c0, c1, 0, 0, 0)
+extern "C" int glp_plonk_setup(glp_ctx* c, uint32_t log_n, uint32_t n_wires, const uint64_t* d_const_vals, const uint64_t* d_sigma_vals,
+                               uint32_t rate_bits, uint32_t cap_height, glp_plonk_circuit** out) {
+    if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
+    if (!d_const_vals || log_n > 24) { glp_set_err(c, "glp_plonk_setup: bad argument"); return GLP_E_INVALID; }
+    const u64 n = 1ull << log_n;
+    DBuf six(c);
+    GLP_HIPCHK(c, six.alloc((size_t)GLP_PLONK_NCONST * n * 8));
+    GLP_HIPCHK(c, hipMemsetAsync(six.p, 0, (size_t)GLP_PLONK_NCONST * n * 8, c->stream));
+    GLP_HIPCHK(c, hipMemcpyAsync(six.p, d_const_vals, (size_t)3 * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    glp_circuit_shape sh;
+    memset(&sh, 0, sizeof(sh));
+    sh.log_n = log_n; sh.n_wires = n_wires; sh.n_routed = n_wires; sh.rate_bits = rate_bits; sh.cap_height = cap_height;
+    return glp_plonk_setup_ex(c, &sh, six.u(), d_sigma_vals, out);
+}
+
 extern "C" void glp_plonk_free(glp_plonk_circuit* ck) { delete ck; }
+
+// witness generation for Poseidon rows: wires 12..129 of every listed row from its wires 0..11 (plonk_gates.h)
+extern "C" int glp_poseidon_gate_fill_rows(glp_ctx* c, uint64_t* d_wire_vals, uint32_t log_n, uint32_t n_wires, const uint32_t* d_rows,
+                                           uint32_t n_rows) {
+    if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
+    if (!d_wire_vals || (!d_rows && n_rows) || log_n > 24 || n_wires < GLP_POS_GATE_WIRES) { glp_set_err(c, "glp_poseidon_gate_fill_rows: bad argument"); return GLP_E_INVALID; }
+    if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set"); return GLP_E_STATE; }
+    if (n_rows == 0) return GLP_OK;
+    hipLaunchKernelGGL(glp_poseidon_gate_fill_kernel<0>, dim3((n_rows + 63) / 64), dim3(64), 0, c->stream, d_wire_vals, 1ull << log_n, d_rows, n_rows,
+                       c->hash->d_consts);
+    GLP_HIPCHK(c, hipGetLastError());
+    return GLP_OK;
+}
 
 extern "C" int glp_plonk_circuit_cap(glp_plonk_circuit* ck, uint64_t* h_cap, size_t* n_words) {
     if (!ck || !n_words || (!h_cap && *n_words)) return GLP_E_INVALID;
@@ -113,7 +155,7 @@ extern "C" int glp_plonk_circuit_cap(glp_plonk_circuit* ck, uint64_t* h_cap, siz
 
 // ---- K6: Z and partial products on the trace domain for given beta, gamma -> zs_vals [NCHAL*M][n] -------
 static int perm_products(glp_ctx* c, glp_plonk_circuit* ck, const u64* d_wire_vals, const u64* beta, const u64* gamma, u64* zs_vals) {
-    const u32 log_n = ck->log_n, W = ck->W, M = W / GLP_PLONK_CHUNK;
+    const u32 log_n = ck->log_n, W = ck->R, M = W / GLP_PLONK_CHUNK;      // W here = the ROUTED wires: rows 0..R-1 of d_wire_vals
     const u64 n = 1ull << log_n;
     const u64* wn_lo = nullptr; const u64* wn_hi = nullptr;
     int rc = glp_ntt_table(c, (int)log_n, 0, &wn_lo, &wn_hi);
@@ -138,13 +180,34 @@ static int perm_products(glp_ctx* c, glp_plonk_circuit* ck, const u64* d_wire_va
     return GLP_OK;
 }
 
+// ---- the public-input polynomial on the LDE domain: values (pi_i on row i < n_public, 0 elsewhere) -> ifft -> coset LDE ----
+static int public_input_lde(glp_ctx* c, glp_plonk_circuit* ck, const u64* h_public, DBuf& pi_lde) {
+    if (ck->n_public == 0) return GLP_OK;
+    const u64 n = 1ull << ck->log_n;
+    u64* v = (u64*)glp_pool_alloc(c, n * 8);
+    if (!v) return GLP_E_NOMEM;
+    DBuf co(c);
+    co.adopt(v);
+    GLP_HIPCHK(c, hipMemsetAsync(v, 0, n * 8, c->stream));
+    GLP_HIPCHK(c, hipMemcpyAsync(v, h_public, (size_t)ck->n_public * 8, hipMemcpyHostToDevice, c->stream));
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));          // h_public is the caller's (pageable) memory
+    int rc = glp_ntt(c, v, ck->log_n, 1, 1);
+    if (rc) return rc;
+    GLP_HIPCHK(c, pi_lde.alloc((n << ck->rate_bits) * 8));
+    return glp_lde_coset(c, v, pi_lde.u(), ck->log_n, ck->rate_bits, 1, 7, GLP_NTT_BITREV);
+}
+
+static u32 n_constraints(const glp_plonk_circuit* ck) {
+    return 2 + 3 * (ck->R / GLP_PLONK_CHUNK) + ((ck->flags & GLP_CIRCUIT_POSEIDON_GATE) ? GLP_POS_GATE_CONSTRAINTS : 0);
+}
+
 // ---- K7: quotient evaluations on the LDE domain (bit-reversed order) for given challenges -> quot_rev [NCHAL][N] ----
-static int quotient_evals(glp_ctx* c, glp_plonk_circuit* ck, const u64* wires_lde, const u64* zs_lde, const u64* beta, const u64* gamma,
-                          const u64* alpha, u64* quot_rev) {
-    const u32 log_n = ck->log_n, W = ck->W, rb = ck->rate_bits, M = W / GLP_PLONK_CHUNK;
+static int quotient_evals(glp_ctx* c, glp_plonk_circuit* ck, const u64* wires_lde, const u64* zs_lde, const u64* pi_lde, const u64* beta,
+                          const u64* gamma, const u64* alpha, u64* quot_rev) {
+    const u32 log_n = ck->log_n, rb = ck->rate_bits;
     const u32 log_N = log_n + rb;
     const u64 n = 1ull << log_n, N = 1ull << log_N;
-    const u32 n_con = 1 + 3 * M;
+    const u32 n_con = n_constraints(ck);
     std::vector<u64> apow((size_t)GLP_PLONK_NCHAL * n_con);
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) { u64 x = 1; for (u32 k = 0; k < n_con; k++) { apow[(size_t)t * n_con + k] = x; x = gl_mul(x, alpha[t]); } }
     DBuf d_apow(c);
@@ -154,17 +217,21 @@ static int quotient_evals(glp_ctx* c, glp_plonk_circuit* ck, const u64* wires_ld
     int rc = glp_ntt_table(c, (int)log_N, 0, &wN_lo, &wN_hi);
     if (rc) return rc;
     GlpQuotientArgs qa;
-    qa.consts = ck->pre.lde.u(); qa.sigmas = ck->pre.lde.u() + 3 * N; qa.wires = wires_lde; qa.zs = zs_lde; qa.ks = ck->ks.u();
-    qa.log_n = log_n; qa.rate_bits = rb; qa.W = W;
+    qa.consts = ck->pre.lde.u(); qa.sigmas = ck->pre.lde.u() + GLP_PLONK_NCONST * N; qa.wires = wires_lde; qa.zs = zs_lde; qa.pi = pi_lde;
+    qa.ks = ck->ks.u();
+    qa.log_n = log_n; qa.rate_bits = rb; qa.W = ck->W; qa.R = ck->R; qa.n_con = n_con;
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) { qa.beta[t] = beta[t]; qa.gamma[t] = gamma[t]; }
-    qa.alpha_pow = d_apow.u(); qa.w_lo = wN_lo; qa.w_hi = wN_hi; qa.shift = ck->shift;
+    qa.alpha_pow = d_apow.u(); qa.pos_consts = c->hash->d_consts; qa.w_lo = wN_lo; qa.w_hi = wN_hi; qa.shift = ck->shift;
     // x^n for natural index e: shift^n * w_N^(e n) = shift^n * w_{2^rb}^(e mod 2^rb)
     const u64 sn = gl_pow(ck->shift, n), wr = gl_root_of_unity(rb);
     for (u32 k = 0; k < (1u << rb); k++) qa.zh_inv[k] = gl_inv(gl_sub(gl_mul(sn, gl_pow(wr, k)), 1));
     qa.n_inv = gl_inv(n % GL_P);
     qa.inv_xm1 = ck->inv_xm1.u();
     qa.out = quot_rev;
-    hipLaunchKernelGGL(glp_quotient_kernel<0>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa);
+    if (ck->flags & GLP_CIRCUIT_POSEIDON_GATE)
+        hipLaunchKernelGGL(glp_quotient_kernel<true>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa);
+    else
+        hipLaunchKernelGGL(glp_quotient_kernel<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa);
     GLP_HIPCHK(c, hipGetLastError());
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));      // apow (host) and d_apow die with this frame
     return GLP_OK;
@@ -181,8 +248,8 @@ static int lde_values(glp_ctx* c, u64* d_vals_owned, u32 n_polys, u32 log_n, u32
 
 // Parity hook for rows a6 / a7: the prover's intermediate stages for CALLER-CHOSEN challenges, so that the HIP output can be
 // compared with an independent restatement (tests/plonk_ref.py::ref_zs / ref_quotient) instead of only through accepted proofs.
-extern "C" int glp_plonk_debug_stage(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, int which, const uint64_t* h_challenges,
-                                     uint64_t* d_out) {
+extern "C" int glp_plonk_debug_stage(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, const uint64_t* h_public, int which,
+                                     const uint64_t* h_challenges, uint64_t* d_out) {
     if (!c) return GLP_E_INVALID;
     GLP_BIND(c);
     if (!ck || !d_wire_vals || !h_challenges || !d_out || (which != GLP_DEBUG_ZS && which != GLP_DEBUG_QUOTIENT)) {
@@ -192,8 +259,9 @@ extern "C" int glp_plonk_debug_stage(glp_ctx* c, glp_plonk_circuit* ck, const ui
     const u32 n_ch = which == GLP_DEBUG_ZS ? 2 * GLP_PLONK_NCHAL : 3 * GLP_PLONK_NCHAL;
     for (u32 i = 0; i < n_ch; i++) if (h_challenges[i] >= GL_P) { glp_set_err(c, "glp_plonk_debug_stage: challenge not canonical"); return GLP_E_INVALID; }
     const u64 *beta = h_challenges, *gamma = h_challenges + GLP_PLONK_NCHAL, *alpha = h_challenges + 2 * GLP_PLONK_NCHAL;
-    const u32 log_n = ck->log_n, W = ck->W, rb = ck->rate_bits, M = W / GLP_PLONK_CHUNK;
+    const u32 log_n = ck->log_n, W = ck->W, rb = ck->rate_bits, M = ck->R / GLP_PLONK_CHUNK;
     const u64 n = 1ull << log_n;
+    if (ck->n_public && !h_public) { glp_set_err(c, "glp_plonk_debug_stage: the circuit has public inputs"); return GLP_E_INVALID; }
     if (which == GLP_DEBUG_ZS) {
         int rc = perm_products(c, ck, d_wire_vals, beta, gamma, d_out);
         if (rc) return rc;
@@ -214,20 +282,30 @@ extern "C" int glp_plonk_debug_stage(glp_ctx* c, glp_plonk_circuit* ck, const ui
     zco.release();
     rc = lde_values(c, zv, GLP_PLONK_NCHAL * M, log_n, rb, zco, zlde);
     if (rc) return rc;
-    return quotient_evals(c, ck, wlde.u(), zlde.u(), beta, gamma, alpha, d_out);
+    DBuf pi_lde(c);
+    rc = public_input_lde(c, ck, h_public, pi_lde);
+    if (rc) return rc;
+    return quotient_evals(c, ck, wlde.u(), zlde.u(), pi_lde.u(), beta, gamma, alpha, d_out);
 }
 
 extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, uint32_t num_queries, uint32_t pow_bits,
                                uint8_t** proof_out, size_t* proof_len) {
+    return glp_plonk_prove_ex(c, ck, d_wire_vals, nullptr, num_queries, pow_bits, proof_out, proof_len);
+}
+
+extern "C" int glp_plonk_prove_ex(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, const uint64_t* h_public, uint32_t num_queries,
+                                  uint32_t pow_bits, uint8_t** proof_out, size_t* proof_len) {
     if (!c) return GLP_E_INVALID;
     GLP_BIND(c);
-    if (!ck || !d_wire_vals || !proof_out || !proof_len || num_queries == 0 || num_queries > 256 || pow_bits > 32) {
+    if (!ck || !d_wire_vals || !proof_out || !proof_len || num_queries == 0 || num_queries > 256 || pow_bits > 32 || (ck->n_public && !h_public)) {
         glp_set_err(c, "glp_plonk_prove: bad argument");
         return GLP_E_INVALID;
     }
+    for (u32 i = 0; i < ck->n_public; i++)
+        if (h_public[i] >= GL_P) { glp_set_err(c, "glp_plonk_prove: public input %u not canonical", i); return GLP_E_INVALID; }
     *proof_out = nullptr; *proof_len = 0;
     if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set"); return GLP_E_STATE; }
-    const u32 log_n = ck->log_n, W = ck->W, rb = ck->rate_bits, M = W / GLP_PLONK_CHUNK;
+    const u32 log_n = ck->log_n, W = ck->W, rb = ck->rate_bits, M = ck->R / GLP_PLONK_CHUNK;
     const u32 log_N = log_n + rb;
     const u64 n = 1ull << log_n, N = 1ull << log_N;
 
@@ -238,7 +316,9 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
     ch.small_mds = c->hash->small_mds;
     std::vector<u64> P;
     auto put = [&](u64 v) { P.push_back(v); ch.observe(v % GL_P); };
-    put(0x31304B4C504C4747ull /* "GGLPLK01" */); put(log_n); put(W); put(rb); put(ck->cap_h);
+    // the statement first: shape, public inputs, the circuit's verifying key — all of it bound before the first challenge
+    put(0x32304B4C504C4747ull /* "GGLPLK02" */); put(log_n); put(W); put(ck->R); put(rb); put(ck->cap_h); put(ck->n_public); put(ck->flags);
+    for (u32 i = 0; i < ck->n_public; i++) put(h_public[i]);
     for (u64 v : ck->pre.cap) put(v);
 
     c->stages.clear(); c->stage_name.clear();
@@ -276,8 +356,12 @@ extern "C" int glp_plonk_prove(glp_ctx* c, glp_plonk_circuit* ck, const uint64_t
     // ---- K7: quotient on the LDE domain --------------------------------------------------------
     DBuf quot_rev(c);
     GLP_HIPCHK(c, quot_rev.alloc((size_t)GLP_PLONK_NCHAL * N * 8));
-    rc = quotient_evals(c, ck, wires.lde.u(), zs.lde.u(), beta, gamma, alpha, quot_rev.u());
+    DBuf pi_lde(c);
+    rc = public_input_lde(c, ck, h_public, pi_lde);
     if (rc) return rc;
+    rc = quotient_evals(c, ck, wires.lde.u(), zs.lde.u(), pi_lde.u(), beta, gamma, alpha, quot_rev.u());
+    if (rc) return rc;
+    pi_lde.reset();
     // evaluations (bit-reversed, coset) -> coefficients: un-bit-reverse, inverse NTT, unshift
     u64* quot_nat = (u64*)glp_pool_alloc(c, (size_t)GLP_PLONK_NCHAL * N * 8);
     if (!quot_nat) return GLP_E_NOMEM;

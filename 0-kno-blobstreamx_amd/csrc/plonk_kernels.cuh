@@ -4,22 +4,23 @@
 // compute_quotient_polys / vanishing_poly::eval_vanishing_poly_base_batch — reference
 // file:line NONE, the mount is empty; the gate set and constraint order here are build-defined).
 //
-// Circuit: n = 2^k rows, W wire columns (all routed, W % 8 == 0).  One gate type, applied to
-// every group of 4 wires (x, y, z, w) of a row:  q * (c0*x*y + c1*z - w) = 0  with per-row
-// constants q (selector), c0, c1.  Copy constraints via the plonky2-style permutation argument
+// Circuit: n = 2^k rows, W wire columns of which the first R are routed (R % 8 == 0); gates: plonk_gates.h
+// (arithmetic/constant on every group of 4 routed wires, public inputs on wire 0, Poseidon rows).
+// Copy constraints via the plonky2-style permutation argument over the routed wires
 // with chunks of 8 wires and num_challenges = 2:
 //   num_j = w_j + beta*k_j*x + gamma,   den_j = w_j + beta*sigma_j + gamma
 //   Z(g x) = Z(x) * prod_c q_c(x),  q_c = prod_{j in chunk c} num_j / den_j,
-//   partial products pi_c = Z * q_0 ... q_c  (c < M-1),  M = W/8 chunks.
+//   partial products pi_c = Z * q_0 ... q_c  (c < M-1),  M = R/8 chunks.
 // Plain HIP C++ without AMD builtins (tests/emu runs these bodies on the CPU).
 #pragma once
 #include "gl_field.cuh"
+#include "plonk_gates.h"
 
 #define GLP_PLONK_CHUNK 8
 #define GLP_PLONK_NCHAL 2
 
 // ---- K6a: per-row chunk quotients ------------------------------------------------------
-// wires, sigmas: [W][n] values on the trace domain (natural order).  ks[j] = k_j.
+// wires: [W][n], sigmas: [R][n] values on the trace domain (natural order); GlpPermArgs::W = R, the routed count.  ks[j] = k_j.
 // qv: [NCHAL][M][n] chunk quotients, rr: [NCHAL][n] row ratios prod_c q_c.
 // xs = table of w_n^i (two-level, forward) to get x = w^i.
 struct GlpPermArgs {
@@ -158,17 +159,21 @@ __global__ void __launch_bounds__(256) glp_scan_apply_kernel(const u64* __restri
 
 // ---- K7: quotient evaluation on the LDE domain ------------------------------------------------
 // All inputs are LDE values, polynomial-major [.][N], bit-reversed index order, N = n << rate_bits.
-// consts: [3][N] = (q, c0, c1); sigmas: [W][N]; wires: [W][N]; zs: [NCHAL*M][N].
+// consts: [GLP_PLONK_NCONST][N] (plonk_gates.h); sigmas: [R][N]; wires: [W][N]; zs: [NCHAL*M][N], M = R/8;
+// pi: [N] the public-input polynomial (null when the circuit has none).
 // Constraint order (index into alpha powers), per challenge t:
 //   0            L_1(x) * (Z(x) - 1)
-//   1 + 3c       prev_c * prod(num) - next_c * prod(den)            chunk c of 8 wires
-//   2 + 3c, 3+3c the two arithmetic gates of chunk c (wires 8c..8c+3 and 8c+4..8c+7)
+//   1            q_pi * wire_0 - PI(x)
+//   2 + 3c       prev_c * prod(num) - next_c * prod(den)            chunk c of 8 routed wires
+//   3+3c, 4+3c   the two arithmetic gates of chunk c (wires 8c..8c+3 and 8c+4..8c+7)
+//   2+3M+k       q_pos * (constraint k of the Poseidon row), k < 118     (POS circuits only)
 // out[t][i] = (sum alpha_t^idx * constraint_idx) / (x^n - 1).
 struct GlpQuotientArgs {
-    const u64* consts; const u64* sigmas; const u64* wires; const u64* zs; const u64* ks;
-    u32 log_n; u32 rate_bits; u32 W;
+    const u64* consts; const u64* sigmas; const u64* wires; const u64* zs; const u64* pi; const u64* ks;
+    u32 log_n; u32 rate_bits; u32 W; u32 R; u32 n_con;
     u64 beta[GLP_PLONK_NCHAL], gamma[GLP_PLONK_NCHAL];
-    const u64* alpha_pow;          // [NCHAL][1 + 3M]
+    const u64* alpha_pow;          // [NCHAL][n_con]
+    const u64* pos_consts;         // POS: rc[360], circ[12], diag[12] on the device
     const u64* w_lo; const u64* w_hi;   // forward table of w_N
     u64 shift;                     // coset shift of the LDE domain
     u64 zh_inv[64];                // 1 / (x^n - 1) for the 2^rate_bits values x^n takes, indexed by (natural index) mod 2^rate_bits
@@ -176,13 +181,13 @@ struct GlpQuotientArgs {
     const u64* inv_xm1;            // [N] 1 / (x_i - 1), bit-reversed order (built once per domain)
     u64* out;                      // [NCHAL][N]
 };
-template <int UNUSED = 0>
+template <bool POS>
 __global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
     const u32 log_N = a.log_n + a.rate_bits;
     const u64 N = 1ull << log_N;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const u32 M = a.W / GLP_PLONK_CHUNK;
+    const u32 M = a.R / GLP_PLONK_CHUNK;
     u64 e = 0;                                   // natural index of this point
     for (u32 b = 0; b < log_N; b++) e |= ((i >> b) & 1ull) << (log_N - 1 - b);
     u64 x = a.w_lo[e & 4095u];
@@ -195,11 +200,13 @@ __global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
     const u64 zhi = a.zh_inv[e & ((1ull << a.rate_bits) - 1)];
     // L_1(x) * (Z - 1) / (x^n - 1) = (Z - 1) / (n (x - 1)): the vanishing factor cancels
     const u64 l1_over_zh = gl_mul(a.n_inv, a.inv_xm1[i]);
-    const u64 q = a.consts[i], c0 = a.consts[N + i], c1 = a.consts[2 * N + i];
+    const u64 q = a.consts[i], c0 = a.consts[N + i], c1 = a.consts[2 * N + i], c2 = a.consts[3 * N + i], q_pi = a.consts[4 * N + i];
     u64 acc[GLP_PLONK_NCHAL], prev[GLP_PLONK_NCHAL], bx[GLP_PLONK_NCHAL];
+    // public inputs (alpha^1)
+    const u64 pi_con = gl_sub(gl_mul(q_pi, a.wires[i]), a.pi ? a.pi[i] : 0ull);
     for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
         const u64 z = a.zs[((u64)t * M) * N + i];
-        acc[t] = 0;
+        acc[t] = gl_mul(a.alpha_pow[(u64)t * a.n_con + 1], pi_con);
         prev[t] = z;
         bx[t] = gl_mul(a.beta[t], x);
     }
@@ -213,8 +220,8 @@ __global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
             kk[jj] = a.ks[j];
         });
         // the two arithmetic gates of this chunk (shared by both challenges up to alpha)
-        const u64 g0 = gl_mul(q, gl_sub(gl_add(gl_mul(c0, gl_mul(w[0], w[1])), gl_mul(c1, w[2])), w[3]));
-        const u64 g1 = gl_mul(q, gl_sub(gl_add(gl_mul(c0, gl_mul(w[4], w[5])), gl_mul(c1, w[6])), w[7]));
+        const u64 g0 = gl_mul(q, glp_arith_gate<GlpGateBase>(c0, c1, c2, w[0], w[1], w[2], w[3]));
+        const u64 g1 = gl_mul(q, glp_arith_gate<GlpGateBase>(c0, c1, c2, w[4], w[5], w[6], w[7]));
         for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
             u64 num = 1, den = 1;
             glp_static_for<0, GLP_PLONK_CHUNK>([&](auto j_) {
@@ -225,17 +232,47 @@ __global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
             });
             const u64 next = (c + 1 < M) ? a.zs[((u64)t * M + 1 + c) * N + i] : a.zs[((u64)t * M) * N + inext];
             const u64 perm = gl_sub(gl_mul(prev[t], num), gl_mul(next, den));
-            const u64* ap = a.alpha_pow + (u64)t * (1 + 3 * M) + 1 + 3 * c;
+            const u64* ap = a.alpha_pow + (u64)t * a.n_con + 2 + 3 * c;
             acc[t] = gl_add(acc[t], gl_mul(ap[0], perm));
             acc[t] = gl_add(acc[t], gl_mul(ap[1], g0));
             acc[t] = gl_add(acc[t], gl_mul(ap[2], g1));
             prev[t] = next;
         }
     }
+    if constexpr (POS) {
+        // one Poseidon row per point: the 118 constraints, each weighted by its alpha power, then the selector once
+        const u64 q_pos = a.consts[5 * N + i];
+        u64 pacc[GLP_PLONK_NCHAL];
+        for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) pacc[t] = 0;
+        u32 k = 0;
+        const u64* ap0 = a.alpha_pow + 2 + 3 * M;
+        glp_poseidon_gate_constraints<GlpGateBase>([&](int j) -> u64 { return a.wires[(u64)j * N + i]; }, a.pos_consts, a.pos_consts + 360,
+                                                   a.pos_consts + 372, [&](u64 con) {
+                                                       for (u32 t = 0; t < GLP_PLONK_NCHAL; t++)
+                                                           pacc[t] = gl_add(pacc[t], gl_mul(ap0[(u64)t * a.n_con + k], con));
+                                                       k++;
+                                                   });
+        for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) acc[t] = gl_add(acc[t], gl_mul(q_pos, pacc[t]));
+    }
     for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
         const u64 z = a.zs[((u64)t * M) * N + i];
         a.out[(u64)t * N + i] = gl_add(gl_mul(acc[t], zhi), gl_mul(l1_over_zh, gl_sub(z, 1)));   // alpha^0 = 1
     }
+}
+
+// ---- Poseidon-row witness: for each listed row, wires 12..129 from wires 0..11 (plonk_gates.h) ----
+// wires: [W][n] values on the trace domain; rows: n_rows row indices; consts: rc[360], circ[12], diag[12] (device)
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(64) glp_poseidon_gate_fill_kernel(u64* __restrict__ wires, u64 n, const u32* __restrict__ rows, u32 n_rows,
+                                                                   const u64* __restrict__ consts) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rows) return;
+    const u64 row = rows[k];
+    if (row >= n) return;
+    u64 in[12], out[GLP_POS_GATE_WIRES - 12];
+    for (int j = 0; j < 12; j++) in[j] = wires[(u64)j * n + row];
+    glp_poseidon_gate_fill(in, consts, consts + 360, consts + 372, out);
+    for (int j = 0; j < GLP_POS_GATE_WIRES - 12; j++) wires[(u64)(12 + j) * n + row] = out[j];
 }
 
 // inv[i] = 1 / (x_i - 1) over the LDE domain (bit-reversed order), 4 points per work-item share

@@ -19,10 +19,11 @@
 #include "glp_ctx.h"
 #include "hash_state.h"
 #include "challenger.h"
+#include "plonk_gates.h"
 
 namespace {
 const u64 FRI_TAG = 0x32304952464C4747ull;
-const u64 PLONK_TAG = 0x31304B4C504C4747ull;
+const u64 PLONK_TAG = 0x32304B4C504C4747ull;   // "GGLPLK02"
 const u32 CHUNK = 8, NCHAL = 2;
 
 struct Reject {
@@ -354,16 +355,19 @@ bool make_hasher_from(const u64* rc, const u64* circ, const u64* diag, Hasher& h
     return true;
 }
 
-// sum_idx alpha_t^idx * C_idx at zeta for challenge t (the constraint list of DESIGN.md §3.6), extension field
-gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 W, const std::vector<u64>& ks, const u64* beta, const u64* gamma, const u64* alpha,
-                       const gl_ext2* consts, const gl_ext2* sigmas, const gl_ext2* wires, const gl_ext2* zs, const gl_ext2* z_next) {
-    const u32 M = W / CHUNK;
+// sum_idx alpha_t^idx * C_idx at zeta for challenge t (the constraint list of plonk_kernels.cuh / DESIGN.md §3.6), extension field
+gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 R, bool poseidon, const u64* pos_consts, const std::vector<u64>& ks, const u64* beta,
+                       const u64* gamma, const u64* alpha, const gl_ext2* consts, const gl_ext2* sigmas, const gl_ext2* wires, const gl_ext2* zs,
+                       const gl_ext2* z_next, gl_ext2 pi_at_x) {
+    typedef GlpGateExt O;
+    const u32 M = R / CHUNK;
     const gl_ext2 one{1, 0};
     // L_1(x) = (x^n - 1) / (n (x - 1))
     const gl_ext2 l1 = gl_ext_mul(gl_ext_sub(xn, one), ext_inv(gl_ext_scale(gl_ext_sub(x, one), n % GL_P)));
-    const gl_ext2 q = consts[0], c0 = consts[1], c1 = consts[2];
+    const gl_ext2 q = consts[0], c0 = consts[1], c1 = consts[2], c2 = consts[3], q_pi = consts[4], q_pos = consts[5];
     gl_ext2 acc = gl_ext_mul(l1, gl_ext_sub(zs[t * M], one));
-    u64 ap = 1;
+    u64 ap = alpha[t];
+    acc = gl_ext_add(acc, gl_ext_scale(gl_ext_sub(gl_ext_mul(q_pi, wires[0]), pi_at_x), ap));       // public inputs, alpha^1
     gl_ext2 prev = zs[t * M];
     const gl_ext2 bx = gl_ext_scale(x, beta[t]);
     for (u32 cidx = 0; cidx < M; cidx++) {
@@ -376,14 +380,38 @@ gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 W, const std::ve
         const gl_ext2 nx = cidx + 1 < M ? zs[t * M + 1 + cidx] : z_next[t];
         const gl_ext2 perm = gl_ext_sub(gl_ext_mul(prev, num), gl_ext_mul(nx, den));
         const gl_ext2* w8 = wires + cidx * CHUNK;
-        const gl_ext2 g0 = gl_ext_mul(q, gl_ext_sub(gl_ext_add(gl_ext_mul(c0, gl_ext_mul(w8[0], w8[1])), gl_ext_mul(c1, w8[2])), w8[3]));
-        const gl_ext2 g1 = gl_ext_mul(q, gl_ext_sub(gl_ext_add(gl_ext_mul(c0, gl_ext_mul(w8[4], w8[5])), gl_ext_mul(c1, w8[6])), w8[7]));
+        const gl_ext2 g0 = gl_ext_mul(q, glp_arith_gate<O>(c0, c1, c2, w8[0], w8[1], w8[2], w8[3]));
+        const gl_ext2 g1 = gl_ext_mul(q, glp_arith_gate<O>(c0, c1, c2, w8[4], w8[5], w8[6], w8[7]));
         const gl_ext2 cons[3] = {perm, g0, g1};
         for (int i = 0; i < 3; i++) {
             ap = gl_mul(ap, alpha[t]);
             acc = gl_ext_add(acc, gl_ext_scale(cons[i], ap));
         }
         prev = nx;
+    }
+    if (poseidon) {
+        gl_ext2 pacc{0, 0};
+        glp_poseidon_gate_constraints<O>([&](int j) -> gl_ext2 { return wires[j]; }, pos_consts, pos_consts + 360, pos_consts + 372,
+                                         [&](gl_ext2 con) {
+                                             ap = gl_mul(ap, alpha[t]);
+                                             pacc = gl_ext_add(pacc, gl_ext_scale(con, ap));
+                                         });
+        acc = gl_ext_add(acc, gl_ext_mul(q_pos, pacc));
+    }
+    return acc;
+}
+
+// PI(x) = sum_i pi_i * L_i(x),  L_i(x) = w^i (x^n - 1) / (n (x - w^i))   (the polynomial that is pi_i on row i < n_public, 0 elsewhere)
+gl_ext2 public_input_poly_at(const u64* pub, u64 n_pub, gl_ext2 x, gl_ext2 xn, u32 log_n) {
+    if (n_pub == 0) return gl_ext2{0, 0};
+    const u64 n = 1ull << log_n, w = gl_root_of_unity(log_n);
+    const gl_ext2 zh_over_n = gl_ext_scale(gl_ext_sub(xn, gl_ext2{1, 0}), gl_inv(n % GL_P));
+    gl_ext2 acc{0, 0};
+    u64 wi = 1;
+    for (u64 i = 0; i < n_pub; i++) {
+        const gl_ext2 li = gl_ext_mul(gl_ext_scale(zh_over_n, wi), ext_inv(gl_ext_sub(x, gl_ext2{wi, 0})));
+        acc = gl_ext_add(acc, gl_ext_scale(li, pub[i]));
+        wi = gl_mul(wi, w);
     }
     return acc;
 }
@@ -412,7 +440,7 @@ static int fri_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, cons
 }
 
 static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, const uint8_t* proof, size_t len, const uint64_t* h_circuit_cap,
-                              size_t cap_words, uint32_t min_queries, uint32_t min_pow_bits) {
+                              size_t cap_words, const uint64_t* h_public, size_t n_public_expected, uint32_t min_queries, uint32_t min_pow_bits) {
     Reader rd{(const u64*)proof, len / 8, 0};
     auto take_obs = [&](size_t k, const u64** out) -> bool {
         if (!rd.take(k, out)) return false;
@@ -420,15 +448,27 @@ static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, co
         return true;
     };
     const u64* hd;
-    if (!take_obs(5, &hd)) return rj.fail("truncated");
-    const u64 tag = hd[0], log_n = hd[1], W = hd[2], rb = hd[3], cap_h = hd[4];
-    if (tag != PLONK_TAG || rb != 3 || W % 8 || W < 8 || W > 128 || log_n < 3 || log_n > 24) return rj.fail("bad plonk header");
+    if (!take_obs(8, &hd)) return rj.fail("truncated");
+    const u64 tag = hd[0], log_n = hd[1], W = hd[2], R = hd[3], rb = hd[4], cap_h = hd[5], n_pub = hd[6], flags = hd[7];
+    if (tag != PLONK_TAG || rb != 3 || W % 8 || W < 8 || W > 160 || R % 8 || R < 8 || R > W || log_n < 3 || log_n > 24 ||
+        n_pub > (1ull << log_n) || (flags & ~(u64)GLP_CIRCUIT_POSEIDON_GATE))
+        return rj.fail("bad plonk header");
+    const bool poseidon = (flags & GLP_CIRCUIT_POSEIDON_GATE) != 0;
+    if (poseidon && (W < GLP_POS_GATE_WIRES || R < 24)) return rj.fail("bad plonk header");
     const u64 n = 1ull << log_n;
-    const u32 log_N = (u32)(log_n + rb), M = (u32)(W / CHUNK);
+    const u32 log_N = (u32)(log_n + rb), M = (u32)(R / CHUNK);
+    const u64* pub;
+    if (!rd.take((size_t)n_pub, &pub)) return rj.fail("truncated");
+    for (u64 i = 0; i < n_pub; i++) {
+        if (pub[i] >= GL_P) return rj.fail("non-canonical public input");
+        ch.observe(pub[i]);
+    }
+    // the proof must be about THIS statement: the caller's public inputs, word for word
+    if (h_public && (n_public_expected != n_pub || memcmp(h_public, pub, (size_t)n_pub * 8) != 0)) return rj.fail("public inputs differ from the expected statement");
     const size_t capw = (size_t)4 << (cap_h < log_N ? cap_h : log_N);
     const u64 *cap_pre, *cap_wires, *cap_zs, *cap_q;
     if (cap_h > 32 || !take_obs(capw, &cap_pre) || !take_obs(capw, &cap_wires)) return rj.fail("truncated");
-    // the proof must be about THIS circuit: its preprocessed commitment is the verifying key
+    // ... and about THIS circuit: its preprocessed commitment is the verifying key
     if (h_circuit_cap && (cap_words != capw || memcmp(h_circuit_cap, cap_pre, capw * 8) != 0)) return rj.fail("preprocessed commitment differs from the circuit's");
     u64 beta[NCHAL], gamma[NCHAL], alpha[NCHAL];
     for (u32 t = 0; t < NCHAL; t++) beta[t] = ch.challenge();
@@ -440,7 +480,7 @@ static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, co
     int rc = fri_verify(rj, h, ch, rd, false, min_queries, min_pow_bits, 1, fi);
     if (rc != GLP_OK) return rc;
     // the FRI part must be about exactly these commitments, shapes and points
-    const u64 want_polys[4] = {3 + W, W, (u64)NCHAL * M, (u64)NCHAL << rb};
+    const u64 want_polys[4] = {GLP_PLONK_NCONST + R, W, (u64)NCHAL * M, (u64)NCHAL << rb};
     if (fi.nb != 4 || fi.log_n != log_n || fi.rb != rb || fi.cap0 != (cap_h < log_N ? cap_h : log_N)) return rj.fail("FRI statement does not match the circuit shape");
     const u64* want_caps[4] = {cap_pre, cap_wires, cap_zs, cap_q};
     for (int b = 0; b < 4; b++) {
@@ -458,18 +498,20 @@ static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, co
     const gl_ext2* zs = fi.openings.data() + fi.open_off[2];
     const gl_ext2* quot = fi.openings.data() + fi.open_off[3];
     const gl_ext2* zs_next = fi.openings.data() + fi.open_off[4];
-    std::vector<u64> ks(W);
+    std::vector<u64> ks(R);
     {
         u64 t = 1;
-        for (u64 j = 0; j < W; j++) { ks[j] = t; t = gl_mul(t, 7); }
+        for (u64 j = 0; j < R; j++) { ks[j] = t; t = gl_mul(t, 7); }
     }
     gl_ext2 zn = fi.zeta;
     for (u64 i = 0; i < log_n; i++) zn = gl_ext_mul(zn, zn);
     const gl_ext2 zh = gl_ext_sub(zn, gl_ext2{1, 0});
+    const gl_ext2 pi_z = public_input_poly_at(pub, n_pub, fi.zeta, zn, (u32)log_n);
     gl_ext2 z_next[NCHAL];
     for (u32 t = 0; t < NCHAL; t++) z_next[t] = zs_next[t * M];
     for (u32 t = 0; t < NCHAL; t++) {
-        const gl_ext2 lhs = constraint_sum(t, fi.zeta, zn, n, (u32)W, ks, beta, gamma, alpha, pre, pre + 3, wires, zs, z_next);
+        const gl_ext2 lhs = constraint_sum(t, fi.zeta, zn, n, (u32)R, poseidon, h.consts.data(), ks, beta, gamma, alpha, pre, pre + GLP_PLONK_NCONST,
+                                           wires, zs, z_next, pi_z);
         gl_ext2 tz{0, 0}, zp{1, 0};
         for (u32 cc = 0; cc < (1u << rb); cc++) {
             tz = gl_ext_add(tz, gl_ext_mul(zp, quot[t * (1u << rb) + cc]));
@@ -493,14 +535,27 @@ extern "C" int glp_fri_verify(glp_ctx* c, const uint8_t* proof, size_t len, uint
     return glp_fri_verify_ex(c, proof, len, min_queries, min_pow_bits, 1, nullptr);
 }
 
-extern "C" int glp_plonk_verify(glp_ctx* c, const uint8_t* proof, size_t len, const uint64_t* h_circuit_cap, size_t cap_words,
-                                uint32_t min_queries, uint32_t min_pow_bits) {
+extern "C" int glp_plonk_verify_ex(glp_ctx* c, const uint8_t* proof, size_t len, const uint64_t* h_circuit_cap, size_t cap_words,
+                                   const uint64_t* h_public, size_t n_public, uint32_t min_queries, uint32_t min_pow_bits) {
     if (!c) return GLP_E_INVALID;
     if (!proof_args_ok(proof, len)) { glp_set_err(c, "glp_plonk_verify: bad argument (proof must be 8-byte aligned words)"); return GLP_E_INVALID; }
     Hasher h;
     glp_challenger ch;
     if (!make_hasher(c, h, ch)) return GLP_E_STATE;
-    return plonk_verify_entry(Reject{c, nullptr, 0}, h, ch, proof, len, h_circuit_cap, cap_words, min_queries, min_pow_bits);
+    return plonk_verify_entry(Reject{c, nullptr, 0}, h, ch, proof, len, h_circuit_cap, cap_words, h_public, n_public, min_queries, min_pow_bits);
+}
+extern "C" int glp_plonk_verify(glp_ctx* c, const uint8_t* proof, size_t len, const uint64_t* h_circuit_cap, size_t cap_words,
+                                uint32_t min_queries, uint32_t min_pow_bits) {
+    return glp_plonk_verify_ex(c, proof, len, h_circuit_cap, cap_words, nullptr, 0, min_queries, min_pow_bits);
+}
+extern "C" int glp_plonk_proof_public_inputs(const uint8_t* proof, size_t len, uint64_t* h_out, size_t* n_words) {
+    if (!proof_args_ok(proof, len) || !n_words || (!h_out && *n_words)) return GLP_E_INVALID;
+    const u64* w = (const u64*)proof;
+    if (len / 8 < 8 || w[0] != PLONK_TAG || w[6] > (1ull << 24) || 8 + w[6] > len / 8) return GLP_E_INVALID;
+    const size_t k = *n_words < w[6] ? *n_words : (size_t)w[6];
+    if (k) memcpy(h_out, w + 8, k * 8);
+    *n_words = (size_t)w[6];
+    return GLP_OK;
 }
 
 // The same verifiers for a host WITHOUT a GPU (a light client, CI): no ctx, the Poseidon constants are passed
@@ -518,12 +573,17 @@ extern "C" int glp_fri_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_c
                                    uint32_t min_queries, uint32_t min_pow_bits, char* err, size_t err_len) {
     return glp_fri_verify_host_ex(h_rc, h_mds_circ, h_mds_diag, proof, len, min_queries, min_pow_bits, 1, nullptr, err, err_len);
 }
-extern "C" int glp_plonk_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* proof, size_t len,
-                                     const uint64_t* h_circuit_cap, size_t cap_words, uint32_t min_queries, uint32_t min_pow_bits, char* err,
-                                     size_t err_len) {
+extern "C" int glp_plonk_verify_host_ex(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* proof, size_t len,
+                                        const uint64_t* h_circuit_cap, size_t cap_words, const uint64_t* h_public, size_t n_public,
+                                        uint32_t min_queries, uint32_t min_pow_bits, char* err, size_t err_len) {
     if (err && err_len) err[0] = 0;
     Hasher h;
     glp_challenger ch;
     if (!proof_args_ok(proof, len) || !make_hasher_from(h_rc, h_mds_circ, h_mds_diag, h, ch)) return GLP_E_INVALID;
-    return plonk_verify_entry(Reject{nullptr, err, err_len}, h, ch, proof, len, h_circuit_cap, cap_words, min_queries, min_pow_bits);
+    return plonk_verify_entry(Reject{nullptr, err, err_len}, h, ch, proof, len, h_circuit_cap, cap_words, h_public, n_public, min_queries, min_pow_bits);
+}
+extern "C" int glp_plonk_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* proof, size_t len,
+                                     const uint64_t* h_circuit_cap, size_t cap_words, uint32_t min_queries, uint32_t min_pow_bits, char* err,
+                                     size_t err_len) {
+    return glp_plonk_verify_host_ex(h_rc, h_mds_circ, h_mds_diag, proof, len, h_circuit_cap, cap_words, nullptr, 0, min_queries, min_pow_bits, err, err_len);
 }

@@ -175,32 +175,63 @@ int glp_fri_prove(glp_ctx* ctx, const glp_fri_config* cfg, const glp_fri_batch* 
 void glp_free_host(void* p);
 
 /* ---- prover for the build-defined circuit (rows a6, a7 + driver; upstream names recalled:
- *      plonk::prover::prove, compute_partial_products_and_z_polys, compute_quotient_polys).
- * Circuit: 2^log_n rows, n_wires columns (all routed, multiple of 8, <= 128);
- * every group of 4 wires (x, y, z, w) of a row satisfies q*(c0*x*y + c1*z - w) = 0; copy
- * constraints through sigma.  d_const_vals: [3][n] = (q, c0, c1) row values; d_sigma_vals:
- * [n_wires][n] with sigma_j(row i) = k_{j'} * w_n^{i'} for the cell (j', i') that (j, i) maps to,
- * k_j = 7^j.  rate_bits must be 3. */
+ *      plonk::prover::prove, compute_partial_products_and_z_polys, compute_quotient_polys, gates::{arithmetic_base,
+ *      constant, public_input, poseidon}).
+ * Circuit: 2^log_n rows, n_wires columns of which the first n_routed take part in the permutation
+ * argument (copy constraints through sigma; the others are advice wires).  Per-row constant columns, in this order:
+ *   [0] q_arith [1] c0 [2] c1 [3] c2 [4] q_pi [5] q_pos          (GLP_PLONK_NCONST = 6)
+ * Gates:
+ *   arithmetic / constant   every group of 4 routed wires (x, y, z, w):  q_arith * (c0*x*y + c1*z + c2 - w) = 0
+ *   public input            q_pi * wire_0 - PI(x) = 0: set q_pi = 1 on rows 0..n_public-1 — wire 0 of row i is public input i
+ *   Poseidon (flag)         a q_pos row carries one permutation with the ctx's constants: wires 0..11 in, 12..23 out,
+ *                           24..129 the S-box inputs of the later rounds (118 degree-7 constraints; fill them with
+ *                           glp_poseidon_gate_fill_rows); set q_arith = 0 on such rows
+ * d_const_vals: [6][n] row values; d_sigma_vals: [n_routed][n] with sigma_j(row i) = k_{j'} * w_n^{i'} for the cell (j', i')
+ * that (j, i) maps to, k_j = 7^j.  rate_bits must be 3: the quotient has degree < 8n (permutation constraint degree 9,
+ * Poseidon row degree 8), so 8 chunks on the 8n-point coset is exactly what fits; it is not a tunable. */
+#define GLP_PLONK_NCONST 6
+#define GLP_CIRCUIT_POSEIDON_GATE 1u
+#define GLP_POS_GATE_WIRES 130
+typedef struct {
+    uint32_t log_n;        /* 3..24 */
+    uint32_t n_wires;      /* multiple of 8, <= 160 */
+    uint32_t n_routed;     /* multiple of 8, 8..n_wires */
+    uint32_t n_public;     /* <= 2^log_n */
+    uint32_t rate_bits;    /* 3 */
+    uint32_t cap_height;   /* <= 12 */
+    uint32_t flags;        /* GLP_CIRCUIT_POSEIDON_GATE: needs n_wires >= GLP_POS_GATE_WIRES and n_routed >= 24 */
+} glp_circuit_shape;
 typedef struct glp_plonk_circuit glp_plonk_circuit;
+int glp_plonk_setup_ex(glp_ctx* ctx, const glp_circuit_shape* shape, const uint64_t* d_const_vals, const uint64_t* d_sigma_vals,
+                       glp_plonk_circuit** out);
+/* the round-1 form: every wire routed, no public inputs, no Poseidon rows, d_const_vals [3][n] = (q, c0, c1) */
 int glp_plonk_setup(glp_ctx* ctx, uint32_t log_n, uint32_t n_wires, const uint64_t* d_const_vals, const uint64_t* d_sigma_vals,
                     uint32_t rate_bits, uint32_t cap_height, glp_plonk_circuit** out);
 void glp_plonk_free(glp_plonk_circuit* ck);
-/* d_wire_vals: [n_wires][n] witness values.  Proof = header, four caps, then the FRI opening
- * proof (all batches at zeta, the Z batch also at w_n*zeta).  Free with glp_free_host. */
+/* d_wire_vals: [n_wires][n] witness values; h_public: n_public canonical words (NULL when the circuit has none).
+ * Proof (little-endian u64 words): header (tag, log_n, n_wires, n_routed, rate_bits, cap_height, n_public, flags), the
+ * public inputs, four caps, then the FRI opening proof (all batches at zeta, the Z batch also at w_n*zeta).  Header, public
+ * inputs and the circuit's cap enter the transcript before the wires cap.  Free with glp_free_host. */
+int glp_plonk_prove_ex(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, const uint64_t* h_public, uint32_t num_queries,
+                       uint32_t pow_bits, uint8_t** proof, size_t* proof_len);
 int glp_plonk_prove(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, uint32_t num_queries, uint32_t pow_bits,
                     uint8_t** proof, size_t* proof_len);
+/* witness generation for Poseidon rows: for each of the n_rows row indices in d_rows (device, u32), wires 12..129 of that row
+ * are computed from its wires 0..11, in place in d_wire_vals [n_wires][2^log_n].  Stream-ordered. */
+int glp_poseidon_gate_fill_rows(glp_ctx* ctx, uint64_t* d_wire_vals, uint32_t log_n, uint32_t n_wires, const uint32_t* d_rows,
+                                uint32_t n_rows);
 
 /* Parity hook for rows a6 / a7: the prover's intermediate stages for CALLER-CHOSEN challenges, so the HIP output can be
  * compared directly with an independent restatement (tests/plonk_ref.py) and not only through accepted proofs.
  *   GLP_DEBUG_ZS:       h_challenges = beta[2], gamma[2];           d_out [2*M][n]  Z then the M-1 partial products per
- *                       challenge, values on the trace domain (M = n_wires / 8)
+ *                       challenge, values on the trace domain (M = n_routed / 8)
  *   GLP_DEBUG_QUOTIENT: h_challenges = beta[2], gamma[2], alpha[2]; d_out [2][8n]   quotient evaluations on the coset
  *                       7*<w_8n>, bit-reversed index order (before the division into chunks)
  * Synchronous.  The prover itself never calls it. */
 #define GLP_DEBUG_ZS 0
 #define GLP_DEBUG_QUOTIENT 1
-int glp_plonk_debug_stage(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, int which, const uint64_t* h_challenges,
-                          uint64_t* d_out);
+int glp_plonk_debug_stage(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, const uint64_t* h_public, int which,
+                          const uint64_t* h_challenges, uint64_t* d_out);
 
 /* the circuit's preprocessed commitment (cap of the constants + sigmas batch) = its verifying key:
  * copies min(*n_words, needed) u64 to h_cap and stores the needed count in *n_words */
@@ -234,6 +265,13 @@ int glp_fri_verify_ex(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, ui
 /* h_circuit_cap (from glp_plonk_circuit_cap; may be NULL = do not bind to a circuit) */
 int glp_plonk_verify(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, const uint64_t* h_circuit_cap, size_t cap_words,
                      uint32_t min_queries, uint32_t min_pow_bits);
+/* ... and to a statement: h_public (NULL = do not bind) must equal the proof's public inputs word for word.  A proof is about
+ * (circuit, public inputs): a verifier that passes NULL for either accepts proofs of OTHER statements. */
+int glp_plonk_verify_ex(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, const uint64_t* h_circuit_cap, size_t cap_words,
+                        const uint64_t* h_public, size_t n_public, uint32_t min_queries, uint32_t min_pow_bits);
+/* the public inputs a proof carries: copies min(*n_words, n_public) words to h_out (may be NULL with *n_words = 0) and stores
+ * n_public in *n_words.  No verification: GLP_E_INVALID when the bytes are not a circuit proof of this format. */
+int glp_plonk_proof_public_inputs(const uint8_t* h_proof, size_t proof_len, uint64_t* h_out, size_t* n_words);
 
 /* The same two verifiers for a host WITHOUT a GPU (a light client, CI): no ctx — the Poseidon constants are
  * passed explicitly (the arguments of glp_set_poseidon_constants: 360, 12, 12 words) and err (may be NULL)
@@ -246,6 +284,9 @@ int glp_fri_verify_host_ex(const uint64_t* h_rc, const uint64_t* h_mds_circ, con
 int glp_plonk_verify_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
                           size_t proof_len, const uint64_t* h_circuit_cap, size_t cap_words, uint32_t min_queries,
                           uint32_t min_pow_bits, char* err, size_t err_len);
+int glp_plonk_verify_host_ex(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
+                             size_t proof_len, const uint64_t* h_circuit_cap, size_t cap_words, const uint64_t* h_public, size_t n_public,
+                             uint32_t min_queries, uint32_t min_pow_bits, char* err, size_t err_len);
 
 /* ---- witness generation (rows a9; upstream names recalled: curta SHA-256/SHA-512 chips) */
 /* n_msgs messages, each already padded to blocks_per_msg 64-byte blocks, [n_msgs][blocks*64].

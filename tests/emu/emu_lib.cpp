@@ -290,25 +290,34 @@ extern "C" int emu_plonk_zs(const u64* wires, const u64* sigmas, u32 log_n, u32 
     return 0;
 }
 
-extern "C" int emu_plonk_quotient(const u64* consts, const u64* sigmas, const u64* wires, const u64* zs, u32 log_n, u32 rb, u32 W,
-                                  const u64* beta, const u64* gamma, const u64* alpha, u64* out) {
-    const u32 log_N = log_n + rb, M = W / GLP_PLONK_CHUNK, n_con = 1 + 3 * M;
+extern "C" int emu_plonk_quotient(const u64* consts, const u64* sigmas, const u64* wires, const u64* zs, const u64* pi, u32 log_n, u32 rb, u32 W,
+                                  u32 R, u32 flags, const u64* pos_consts, const u64* beta, const u64* gamma, const u64* alpha, u64* out) {
+    const u32 log_N = log_n + rb, M = R / GLP_PLONK_CHUNK;
+    const u32 n_con = 2 + 3 * M + ((flags & GLP_CIRCUIT_POSEIDON_GATE) ? GLP_POS_GATE_CONSTRAINTS : 0);
     const u64 n = 1ull << log_n, N = 1ull << log_N;
-    std::vector<u64> lo(glp_table_lo_len(log_N)), hi(glp_table_hi_len(log_N) ? glp_table_hi_len(log_N) : 1), ks(W), inv(N);
+    std::vector<u64> lo(glp_table_lo_len(log_N)), hi(glp_table_hi_len(log_N) ? glp_table_hi_len(log_N) : 1), ks(R), inv(N);
     glp_fill_table(log_N, 0, lo.data(), hi.data());
     const u64* hip = glp_table_hi_len(log_N) ? hi.data() : nullptr;
-    { u64 t = 1; for (u32 j = 0; j < W; j++) { ks[j] = t; t = gl_mul(t, 7); } }
+    { u64 t = 1; for (u32 j = 0; j < R; j++) { ks[j] = t; t = gl_mul(t, 7); } }
     glp_emu_launch((unsigned)((N / 4 + 63) / 64), 64, 0, [&] { glp_inv_xm1_kernel<0>(inv.data(), log_N, 7, lo.data(), hip); });
     std::vector<u64> apow((size_t)GLP_PLONK_NCHAL * n_con);
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) { u64 x = 1; for (u32 k = 0; k < n_con; k++) { apow[(size_t)t * n_con + k] = x; x = gl_mul(x, alpha[t]); } }
     GlpQuotientArgs qa;
-    qa.consts = consts; qa.sigmas = sigmas; qa.wires = wires; qa.zs = zs; qa.ks = ks.data(); qa.log_n = log_n; qa.rate_bits = rb; qa.W = W;
+    qa.consts = consts; qa.sigmas = sigmas; qa.wires = wires; qa.zs = zs; qa.pi = pi; qa.ks = ks.data();
+    qa.log_n = log_n; qa.rate_bits = rb; qa.W = W; qa.R = R; qa.n_con = n_con;
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) { qa.beta[t] = beta[t]; qa.gamma[t] = gamma[t]; }
-    qa.alpha_pow = apow.data(); qa.w_lo = lo.data(); qa.w_hi = hip; qa.shift = 7;
+    qa.alpha_pow = apow.data(); qa.pos_consts = pos_consts; qa.w_lo = lo.data(); qa.w_hi = hip; qa.shift = 7;
     const u64 sn = gl_pow(7, n), wr = gl_root_of_unity(rb);
     for (u32 k = 0; k < (1u << rb); k++) qa.zh_inv[k] = gl_inv(gl_sub(gl_mul(sn, gl_pow(wr, k)), 1));
     qa.n_inv = gl_inv(n % GL_P); qa.inv_xm1 = inv.data(); qa.out = out;
-    glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<0>(qa); });
+    if (flags & GLP_CIRCUIT_POSEIDON_GATE) glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<true>(qa); });
+    else glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<false>(qa); });
+    return 0;
+}
+
+// Poseidon-row witness through the product's kernel: wires [W][n] in place, for the listed rows
+extern "C" int emu_poseidon_gate_fill_rows(u64* wires, u32 log_n, const u32* rows, u32 n_rows, const u64* pos_consts) {
+    glp_emu_launch((n_rows + 63) / 64, 64, 0, [&] { glp_poseidon_gate_fill_kernel<0>(wires, 1ull << log_n, rows, n_rows, pos_consts); });
     return 0;
 }
 

@@ -18,6 +18,7 @@ import plonk_ref as pref  # noqa: E402
 from conftest import poseidon_consts, rand_field  # noqa: E402
 
 PLONK = {"seed": 20261004, "log_n": 6, "W": 8, "queries": 8, "pow_bits": 4}
+GATES = {"seed": 424242, "log_n": 5, "W": 136, "R": 24, "n_public": 2, "pos_rows": [3, 17, 18], "queries": 4, "pow_bits": 3}
 FRI = {"seed": 77001, "log_n": 8, "polys": [3, 2], "rate_bits": 3, "cap_height": 2, "arity_bits": 2, "final_poly_bits": 3, "queries": 6,
        "pow_bits": 5}
 
@@ -30,6 +31,12 @@ def make(pkg, prover):
     plonk_proof = ck.prove(c["wires"], PLONK["queries"], PLONK["pow_bits"])
     cap = ck.cap()
     ck.free()
+    g = pref.build_circuit(np.random.default_rng(GATES["seed"]), GATES["log_n"], GATES["W"], n_routed=GATES["R"], n_public=GATES["n_public"],
+                           poseidon_rows=GATES["pos_rows"], consts=(rc, circ, diag))
+    gk = pkg.PlonkCircuit(prover, g["consts"], g["sigmas"], n_wires=GATES["W"], n_public=GATES["n_public"], poseidon=True)
+    gates_proof = gk.prove(g["wires"], GATES["queries"], GATES["pow_bits"], public=g["public"])
+    gates_cap = gk.cap()
+    gk.free()
     rng = np.random.default_rng(FRI["seed"])
     batches = [pkg.PolynomialBatch.from_values(prover, rand_field(rng, (k, 1 << FRI["log_n"])), FRI["rate_bits"], FRI["cap_height"])
                for k in FRI["polys"]]
@@ -39,6 +46,7 @@ def make(pkg, prover):
         b.free()
     return {"note": "made by tests/golden/gen_proofs.py on an MI355X; Poseidon constants = poseidon_constants.default_constants()",
             "plonk": dict(PLONK, circuit_cap=[int(v) for v in cap], proof=plonk_proof.hex()),
+            "gates": dict(GATES, public=[int(v) for v in g["public"]], circuit_cap=[int(v) for v in gates_cap], proof=gates_proof.hex()),
             "fri": dict(FRI, proof=fri_proof.hex())}
 
 
@@ -47,6 +55,6 @@ if __name__ == "__main__":
     pr = pkg.Prover(0)
     out = make(pkg, pr)
     pr.close()
-    with open(os.path.join(HERE, "proofs.json"), "w") as f:
+    with open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "proofs.json"), "w") as f:
         json.dump(out, f)
-    print("wrote proofs.json:", len(out["plonk"]["proof"]) // 2, "+", len(out["fri"]["proof"]) // 2, "bytes")
+    print("wrote proofs.json:", len(out["plonk"]["proof"]) // 2, "+", len(out["gates"]["proof"]) // 2, "+", len(out["fri"]["proof"]) // 2, "bytes")

@@ -1,7 +1,8 @@
-"""TEST INFRASTRUCTURE for the build-defined circuit of DESIGN.md §3.6: a random satisfiable
-circuit generator, Python big-int restatements of the permutation products (row a6) and of
-the quotient on the LDE domain (row a7), and an independent verifier of the whole proof
-(transcript replay + the PLONK identity at zeta on top of tests/fri_verifier.py)."""
+"""TEST INFRASTRUCTURE for the build-defined circuit of DESIGN.md §3.6: a random satisfiable circuit generator
+(arithmetic / constant gates, public inputs, Poseidon rows, copy constraints over the routed wires), Python big-int
+restatements of the permutation products (row a6) and of the quotient on the LDE domain (row a7), a big-int Poseidon row
+(witness + the 118 constraints), and an independent verifier of the whole proof (transcript replay + the PLONK identity
+at zeta on top of tests/fri_verifier.py).  Shares no code with the product."""
 import numpy as np
 
 import fri_verifier as fv
@@ -9,7 +10,11 @@ import fri_verifier as fv
 P = fv.P
 CHUNK = 8
 NCHAL = 2
-TAG = 0x31304B4C504C4747
+NCONST = 6                     # q_arith, c0, c1, c2, q_pi, q_pos
+TAG = 0x32304B4C504C4747       # "GGLPLK02"
+FLAG_POSEIDON = 1
+POS_WIRES = 130
+POS_CONSTRAINTS = 118
 
 
 def ks_of(W):
@@ -20,14 +25,130 @@ def ks_of(W):
     return out
 
 
-def build_circuit(rng, log_n, W, copy_prob=0.5):
-    """random satisfiable instance: returns consts [3][n], sigma_vals [W][n], wires [W][n] (uint64)"""
+# ---- field helpers: the same formulas over ints (base field) or pairs (quadratic extension) ------------------------------
+class Base:
+    zero = 0
+    add = staticmethod(lambda a, b: (a + b) % P)
+    sub = staticmethod(lambda a, b: (a - b) % P)
+    mul = staticmethod(lambda a, b: a * b % P)
+    scale = staticmethod(lambda a, k: a * k % P)
+    addc = staticmethod(lambda a, k: (a + k) % P)
+    emb = staticmethod(lambda v: v % P)
+
+
+class Ext:
+    zero = (0, 0)
+    add = staticmethod(fv.eadd)
+    sub = staticmethod(fv.esub)
+    mul = staticmethod(fv.emul)
+    scale = staticmethod(fv.escale)
+    addc = staticmethod(lambda a, k: ((a[0] + k) % P, a[1]))
+    emb = staticmethod(lambda v: (v % P, 0))
+
+
+# ---- Poseidon row (width 12, x^7, 4 + 22 + 4 rounds; round = add constants, S-box, MDS) ------------------------------------
+def _mds(F, s, circ, diag, rc_next):
+    out = []
+    for r in range(12):
+        acc = F.scale(s[r], diag[r])
+        for i in range(12):
+            acc = F.add(acc, F.scale(s[(i + r) % 12], circ[i]))
+        out.append(F.addc(acc, rc_next[r]) if rc_next is not None else acc)
+    return out
+
+
+def _sbox(F, x):
+    x2 = F.mul(x, x)
+    x3 = F.mul(x2, x)
+    x4 = F.mul(x2, x2)
+    return F.mul(x3, x4)
+
+
+def poseidon_row(inputs, consts):
+    """the 130 wire values of a Poseidon row from its 12 inputs: in, out, then the S-box inputs of every round after the
+    first (3 x 12 full, 22 partial lane-0 values, 4 x 12 full).  consts = (rc[360], circ[12], diag[12]) as ints."""
+    rc, circ, diag = consts
+    F = Base
+    s = [F.addc(inputs[i], rc[i]) for i in range(12)]
+    adv = []
+    rnd = 0
+    for r in range(4):
+        if r > 0:
+            adv += s
+        s = [_sbox(F, v) for v in s]
+        s = _mds(F, s, circ, diag, rc[(rnd + 1) * 12:(rnd + 2) * 12])
+        rnd += 1
+    for r in range(22):
+        adv.append(s[0])
+        s[0] = _sbox(F, s[0])
+        s = _mds(F, s, circ, diag, rc[(rnd + 1) * 12:(rnd + 2) * 12])
+        rnd += 1
+    for r in range(4):
+        adv += s
+        s = [_sbox(F, v) for v in s]
+        s = _mds(F, s, circ, diag, rc[(rnd + 1) * 12:(rnd + 2) * 12] if rnd + 1 < 30 else None)
+        rnd += 1
+    return list(inputs) + s + adv
+
+
+def poseidon_constraints(F, wires, consts):
+    """the 118 constraint values of a Poseidon row at one point; wires = the row's first 130 wire values (F elements)"""
+    rc, circ, diag = consts
+    s = [F.addc(wires[i], rc[i]) for i in range(12)]
+    out = []
+    rnd, aw = 0, 24
+    for r in range(4):
+        if r > 0:
+            for i in range(12):
+                out.append(F.sub(wires[aw + i], s[i]))
+            s = list(wires[aw:aw + 12])
+            aw += 12
+        s = [_sbox(F, v) for v in s]
+        s = _mds(F, s, circ, diag, rc[(rnd + 1) * 12:(rnd + 2) * 12])
+        rnd += 1
+    for r in range(22):
+        p = wires[aw]
+        aw += 1
+        out.append(F.sub(p, s[0]))
+        s[0] = _sbox(F, p)
+        s = _mds(F, s, circ, diag, rc[(rnd + 1) * 12:(rnd + 2) * 12])
+        rnd += 1
+    for r in range(4):
+        for i in range(12):
+            out.append(F.sub(wires[aw + i], s[i]))
+        s = [_sbox(F, v) for v in wires[aw:aw + 12]]
+        aw += 12
+        s = _mds(F, s, circ, diag, rc[(rnd + 1) * 12:(rnd + 2) * 12] if rnd + 1 < 30 else None)
+        rnd += 1
+    for i in range(12):
+        out.append(F.sub(wires[12 + i], s[i]))
+    assert len(out) == POS_CONSTRAINTS and aw == POS_WIRES
+    return out
+
+
+def int_consts(consts):
+    return tuple([int(v) for v in a] for a in consts)
+
+
+# ---- circuit generator -------------------------------------------------------------------------------------------------------
+def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, poseidon_rows=(), consts=None, public_values=None):
+    """random satisfiable instance.  Returns a dict: consts [6][n], sigmas [R][n], wires [W][n] (uint64), public (list of ints),
+    shape fields.  poseidon_rows: row indices that carry a permutation (needs W >= 130, R >= 24 and the Poseidon constants);
+    n_public: rows 0..n_public-1 expose wire 0 as a public input (public_values: what those cells must hold; default random)."""
     n = 1 << log_n
-    G = W // 4
+    R = W if n_routed is None else n_routed
+    G = R // 4
+    pos = set(int(r) for r in poseidon_rows)
+    if pos:
+        assert W >= POS_WIRES and R >= 24 and consts is not None
+        consts = int_consts(consts)
     rnd = lambda: int(rng.integers(0, 1 << 62)) * 4 % P
-    q = [1 if rng.random() < 0.8 else 0 for _ in range(n)]
+    q = [0 if i in pos else (1 if rng.random() < 0.8 else 0) for i in range(n)]
     c0 = [rnd() for _ in range(n)]
     c1 = [rnd() for _ in range(n)]
+    c2 = [rnd() if rng.random() < 0.5 else 0 for _ in range(n)]
+    q_pi = [1 if i < n_public else 0 for i in range(n)]
+    q_pos = [1 if i in pos else 0 for i in range(n)]
     wires = [[0] * n for _ in range(W)]
     parent = {}
 
@@ -43,46 +164,70 @@ def build_circuit(rng, log_n, W, copy_prob=0.5):
             parent[ra] = rb
 
     cells = []
+
+    def fresh_or_copy(j, i):
+        if j == 0 and i < n_public and public_values is not None:
+            wires[j][i] = int(public_values[i]) % P
+            cells.append((j, i))
+            return
+        if cells and rng.random() < copy_prob:
+            src = cells[int(rng.integers(0, len(cells)))]
+            wires[j][i] = wires[src[0]][src[1]]
+            union((j, i), src)
+        else:
+            wires[j][i] = rnd()
+        cells.append((j, i))
+
     for i in range(n):
+        if i in pos:
+            for j in range(12):
+                fresh_or_copy(j, i)                       # inputs: free cells (copies of earlier outputs chain permutations)
+            row = poseidon_row([wires[j][i] for j in range(12)], consts)
+            for j in range(12, POS_WIRES):
+                wires[j][i] = row[j]
+                if j < R:
+                    cells.append((j, i))                  # determined cells: may be copied FROM
+            for j in range(POS_WIRES, W):
+                wires[j][i] = rnd()
+                if j < R:
+                    cells.append((j, i))
+            continue
         for g in range(G):
             for k in range(3):          # inputs x, y, z
-                j = 4 * g + k
-                if cells and rng.random() < copy_prob:
-                    src = cells[int(rng.integers(0, len(cells)))]
-                    wires[j][i] = wires[src[0]][src[1]]
-                    union((j, i), src)
-                else:
-                    wires[j][i] = rnd()
-                cells.append((j, i))
+                fresh_or_copy(4 * g + k, i)
             x, y, z = wires[4 * g][i], wires[4 * g + 1][i], wires[4 * g + 2][i]
-            wires[4 * g + 3][i] = (c0[i] * x * y + c1[i] * z) % P if q[i] else rnd()
+            wires[4 * g + 3][i] = (c0[i] * x * y + c1[i] * z + c2[i]) % P if q[i] else rnd()
             cells.append((4 * g + 3, i))
-    # sigma: one cycle per equivalence class
+        for j in range(R, W):
+            wires[j][i] = rnd()                           # advice wires: unconstrained outside Poseidon rows
+    # sigma: one cycle per equivalence class (routed wires only)
     classes = {}
-    for j in range(W):
+    for j in range(R):
         for i in range(n):
             classes.setdefault(find((j, i)), []).append((j, i))
-    ks = ks_of(W)
+    ks = ks_of(R)
     w = fv.root(log_n)
     wp = [1] * n
     for i in range(1, n):
         wp[i] = wp[i - 1] * w % P
-    sigma = [[0] * n for _ in range(W)]
+    sigma = [[0] * n for _ in range(R)]
     for members in classes.values():
         for a, (j, i) in enumerate(members):
             jj, ii = members[(a + 1) % len(members)]
             sigma[j][i] = ks[jj] * wp[ii] % P
     to_np = lambda rows: np.array(rows, dtype=np.uint64)
-    return {"log_n": log_n, "W": W, "consts": to_np([q, c0, c1]), "sigmas": to_np(sigma), "wires": to_np(wires)}
+    return {"log_n": log_n, "W": W, "R": R, "n_public": n_public, "flags": FLAG_POSEIDON if pos else 0,
+            "consts": to_np([q, c0, c1, c2, q_pi, q_pos]), "sigmas": to_np(sigma), "wires": to_np(wires),
+            "public": [wires[0][i] for i in range(n_public)], "pos_consts": consts}
 
 
 def ref_zs(circ, beta, gamma):
-    """[NCHAL*M][n]: per challenge Z then pi_0 .. pi_{M-2}, by the definition"""
-    n, W = 1 << circ["log_n"], circ["W"]
-    M = W // CHUNK
-    ks = ks_of(W)
+    """[NCHAL*M][n]: per challenge Z then pi_0 .. pi_{M-2}, by the definition (routed wires only)"""
+    n, R = 1 << circ["log_n"], circ["R"]
+    M = R // CHUNK
+    ks = ks_of(R)
     w = fv.root(circ["log_n"])
-    wires = [[int(v) for v in r] for r in circ["wires"]]
+    wires = [[int(v) for v in r] for r in circ["wires"][:R]]
     sig = [[int(v) for v in r] for r in circ["sigmas"]]
     out = []
     for t in range(NCHAL):
@@ -108,55 +253,73 @@ def ref_zs(circ, beta, gamma):
     return np.array(out, dtype=np.uint64)
 
 
-def constraint_sum(t, x, n, W, ks, beta, gamma, alpha, consts, sigmas, wires, zs, z_next, ext=False):
-    """sum_idx alpha_t^idx * C_idx at a point; values are ints (base field) or ext pairs"""
-    M = W // CHUNK
-    if ext:
-        add, sub, mul = fv.eadd, fv.esub, fv.emul
-        emb = lambda v: (v % P, 0)
-        xn = x
-        for _ in range(n.bit_length() - 1):
-            xn = fv.emul(xn, xn)
-        l1 = fv.emul(fv.esub(xn, (1, 0)), fv.einv(fv.escale(fv.esub(x, (1, 0)), n % P)))
-    else:
-        add = lambda a, b: (a + b) % P
-        sub = lambda a, b: (a - b) % P
-        mul = lambda a, b: a * b % P
-        emb = lambda v: v % P
-        l1 = (pow(x, n, P) - 1) * pow(n * (x - 1) % P, P - 2, P) % P
-    one = emb(1)
-    q, c0, c1 = consts
-    acc = mul(l1, sub(zs[t * M], one))
-    ap = 1
+def public_input_poly_at(F, public, x, log_n):
+    """PI(x) = sum_i pi_i L_i(x), L_i = w^i (x^n - 1) / (n (x - w^i)): pi_i on row i < len(public), 0 on every other row"""
+    n = 1 << log_n
+    w = fv.root(log_n)
+    xn = x
+    for _ in range(log_n):
+        xn = F.mul(xn, xn)
+    zh_over_n = F.scale(F.sub(xn, F.emb(1)), pow(n, P - 2, P))
+    inv = (lambda v: pow(v, P - 2, P)) if F is Base else fv.einv
+    acc, wi = F.zero, 1
+    for pv in public:
+        li = F.mul(F.scale(zh_over_n, wi), inv(F.sub(x, F.emb(wi))))
+        acc = F.add(acc, F.scale(li, pv % P))
+        wi = wi * w % P
+    return acc
+
+
+def constraint_sum(t, x, n, R, ks, beta, gamma, alpha, consts, sigmas, wires, zs, z_next, pi_at_x, ext=False, pos_consts=None):
+    """sum_idx alpha_t^idx * C_idx at a point; values are ints (base field) or ext pairs.  Constraint order: 0 L_1 (Z - 1),
+    1 public inputs, then per chunk (perm, gate, gate), then (Poseidon circuits) the 118 row constraints times q_pos."""
+    F = Ext if ext else Base
+    M = R // CHUNK
+    one = F.emb(1)
+    xn = x
+    for _ in range(n.bit_length() - 1):
+        xn = F.mul(xn, xn)
+    inv = fv.einv if ext else (lambda v: pow(v, P - 2, P))
+    l1 = F.mul(F.sub(xn, one), inv(F.scale(F.sub(x, one), n % P)))
+    q, c0, c1, c2, q_pi, q_pos = consts
+    acc = F.mul(l1, F.sub(zs[t * M], one))
+    ap = alpha[t]
+    acc = F.add(acc, F.scale(F.sub(F.mul(q_pi, wires[0]), pi_at_x), ap))
     prev = zs[t * M]
-    bx = mul(emb(beta[t]), x)
+    bx = F.scale(x, beta[t])
     for c in range(M):
         num, den = one, one
         for j in range(c * CHUNK, (c + 1) * CHUNK):
-            wg = add(wires[j], emb(gamma[t]))
-            num = mul(num, add(wg, mul(bx, emb(ks[j]))))
-            den = mul(den, add(wg, mul(emb(beta[t]), sigmas[j])))
+            wg = F.addc(wires[j], gamma[t])
+            num = F.mul(num, F.add(wg, F.scale(bx, ks[j])))
+            den = F.mul(den, F.add(wg, F.scale(sigmas[j], beta[t])))
         nxt = zs[t * M + 1 + c] if c + 1 < M else z_next[t]
-        perm = sub(mul(prev, num), mul(nxt, den))
+        perm = F.sub(F.mul(prev, num), F.mul(nxt, den))
         w8 = wires[c * CHUNK:(c + 1) * CHUNK]
-        g0 = mul(q, sub(add(mul(c0, mul(w8[0], w8[1])), mul(c1, w8[2])), w8[3]))
-        g1 = mul(q, sub(add(mul(c0, mul(w8[4], w8[5])), mul(c1, w8[6])), w8[7]))
-        for con in (perm, g0, g1):
+        gate = lambda xx, yy, zz, ww: F.mul(q, F.sub(F.add(F.add(F.mul(c0, F.mul(xx, yy)), F.mul(c1, zz)), c2), ww))
+        for con in (perm, gate(*w8[0:4]), gate(*w8[4:8])):
             ap = ap * alpha[t] % P
-            acc = add(acc, mul(emb(ap), con))
+            acc = F.add(acc, F.scale(con, ap))
         prev = nxt
+    if pos_consts is not None:
+        pacc = F.zero
+        for con in poseidon_constraints(F, wires, pos_consts):
+            ap = ap * alpha[t] % P
+            pacc = F.add(pacc, F.scale(con, ap))
+        acc = F.add(acc, F.mul(q_pos, pacc))
     return acc
 
 
 def ref_quotient(circ, lde, beta, gamma, alpha, rate_bits=3):
-    """quotient values on the LDE domain, bit-reversed order: lde = dict of bit-reversed LDE value
-    matrices (consts, sigmas, wires, zs) as lists of int rows.  Returns [NCHAL][N] ints."""
-    log_n, W = circ["log_n"], circ["W"]
+    """quotient values on the LDE domain, bit-reversed order: lde = dict of bit-reversed LDE value matrices (consts, sigmas,
+    wires, zs) as lists of int rows.  The public-input polynomial is evaluated by its definition.  Returns [NCHAL][N] ints."""
+    log_n, R = circ["log_n"], circ["R"]
     n, log_N = 1 << log_n, log_n + rate_bits
     N = 1 << log_N
-    M = W // CHUNK
-    ks = ks_of(W)
+    M = R // CHUNK
+    ks = ks_of(R)
     wN = fv.root(log_N)
+    pos_consts = circ["pos_consts"] if circ["flags"] & FLAG_POSEIDON else None
     out = [[0] * N for _ in range(NCHAL)]
     for i in range(N):
         e = fv.rev(i, log_N)
@@ -166,14 +329,17 @@ def ref_quotient(circ, lde, beta, gamma, alpha, rate_bits=3):
         col = lambda mat, idx=i: [r[idx] for r in mat]
         zs_i = col(lde["zs"])
         z_next = [lde["zs"][t * M][inext] for t in range(NCHAL)]
+        pi_x = public_input_poly_at(Base, circ["public"], x, log_n)
         for t in range(NCHAL):
-            v = constraint_sum(t, x, n, W, ks, beta, gamma, alpha, col(lde["consts"]), col(lde["sigmas"]), col(lde["wires"]), zs_i, z_next)
+            v = constraint_sum(t, x, n, R, ks, beta, gamma, alpha, col(lde["consts"]), col(lde["sigmas"]), col(lde["wires"]), zs_i, z_next, pi_x,
+                               pos_consts=pos_consts)
             out[t][i] = v * zh_inv % P
     return out
 
 
-def verify_plonk(proof_bytes, oracle):
-    """independent verifier of glp_plonk_prove's output; raises fv.VerifyError"""
+def verify_plonk(proof_bytes, oracle, pos_consts=None, public=None):
+    """independent verifier of glp_plonk_prove's output; raises fv.VerifyError.  pos_consts = (rc, circ, diag): needed for
+    Poseidon-gate circuits (the constants the gate is about).  public: the expected public inputs (None = take the proof's)."""
     words = np.frombuffer(proof_bytes, dtype="<u8")
     h = fv.Hasher(oracle)
     ch = fv.Challenger(h)
@@ -189,11 +355,20 @@ def verify_plonk(proof_bytes, oracle):
             ch.observe(v)
         return out
 
-    tag, log_n, W, rb, cap_h = take(5)
-    if tag != TAG or rb != 3 or W % 8 or not (8 <= W <= 128) or not (3 <= log_n <= 24):
+    tag, log_n, W, R, rb, cap_h, n_pub, flags = take(8)
+    if tag != TAG or rb != 3 or W % 8 or not (8 <= W <= 160) or R % 8 or not (8 <= R <= W) or not (3 <= log_n <= 24) or n_pub > (1 << log_n) \
+            or flags & ~FLAG_POSEIDON:
         raise fv.VerifyError("bad plonk header")
+    poseidon = bool(flags & FLAG_POSEIDON)
+    if poseidon and (W < POS_WIRES or R < 24 or pos_consts is None):
+        raise fv.VerifyError("Poseidon-gate circuit: bad shape or constants not supplied")
+    pub = take(n_pub)
+    if any(v >= P for v in pub):
+        raise fv.VerifyError("non-canonical public input")
+    if public is not None and [int(v) for v in public] != pub:
+        raise fv.VerifyError("public inputs differ from the expected statement")
     n, log_N = 1 << log_n, log_n + rb
-    M = W // CHUNK
+    M = R // CHUNK
     capw = 4 << min(cap_h, log_N)
     cap_pre = take(capw)
     cap_wires = take(capw)
@@ -205,7 +380,7 @@ def verify_plonk(proof_bytes, oracle):
     info = fv.parse_and_verify(None, oracle, challenger=ch, words=words, pos=pos)
     # the FRI part must be about exactly these commitments, shapes and points
     flat = lambda cap: [v for d in cap for v in d]
-    if info["n_polys"] != [3 + W, W, NCHAL * M, NCHAL << rb] or info["log_n"] != log_n or info["rate_bits"] != rb:
+    if info["n_polys"] != [NCONST + R, W, NCHAL * M, NCHAL << rb] or info["log_n"] != log_n or info["rate_bits"] != rb:
         raise fv.VerifyError("FRI statement does not match the circuit shape")
     if [flat(c) for c in info["caps"]] != [cap_pre, cap_wires, cap_zs, cap_q]:
         raise fv.VerifyError("FRI caps differ from the committed caps")
@@ -215,18 +390,22 @@ def verify_plonk(proof_bytes, oracle):
     zeta = info["zeta"]
     pre, wires, zs, quot = (info["openings_at"][(0, b)] for b in range(4))
     zs_next = info["openings_at"][(1, 2)]
-    consts, sigmas = pre[:3], pre[3:]
-    ks = ks_of(W)
+    consts, sigmas = pre[:NCONST], pre[NCONST:]
+    ks = ks_of(R)
     zn = zeta
     for _ in range(log_n):
         zn = fv.emul(zn, zn)
     zh = fv.esub(zn, (1, 0))
+    pi_z = public_input_poly_at(Ext, pub, zeta, log_n)
+    pc = int_consts(pos_consts) if poseidon else None
     for t in range(NCHAL):
-        lhs = constraint_sum(t, zeta, n, W, ks, beta, gamma, alpha, consts, sigmas, wires, zs, [zs_next[tt * M] for tt in range(NCHAL)], ext=True)
+        lhs = constraint_sum(t, zeta, n, R, ks, beta, gamma, alpha, consts, sigmas, wires, zs, [zs_next[tt * M] for tt in range(NCHAL)], pi_z,
+                             ext=True, pos_consts=pc)
         tz, zp = (0, 0), (1, 0)
         for c in range(1 << rb):
             tz = fv.eadd(tz, fv.emul(zp, quot[t * (1 << rb) + c]))
             zp = fv.emul(zp, zn)
         if lhs != fv.emul(zh, tz):
             raise fv.VerifyError(f"PLONK identity fails for challenge {t}")
-    return {"log_n": log_n, "W": W, "beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "fri": info}
+    return {"log_n": log_n, "W": W, "R": R, "public": pub, "flags": flags, "beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta,
+            "fri": info}

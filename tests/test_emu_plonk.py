@@ -9,7 +9,7 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fri_verifier as fv  # noqa: E402
 import plonk_ref as pr  # noqa: E402
-from conftest import P, ptr, rand_field  # noqa: E402
+from conftest import P, poseidon_consts, ptr, rand_field  # noqa: E402
 
 
 def lde_bitrev(oracle, vals, log_n, rb):
@@ -44,27 +44,32 @@ def test_broken_copy_constraint_is_detected_by_reference():
         pr.ref_zs(circ, [3, 5], [7, 11])
 
 
-@pytest.mark.parametrize("log_n,W", [(3, 8), (4, 16)])
-def test_quotient_on_lde_domain(emu, oracle, log_n, W):
-    rb = 3
-    rng = np.random.default_rng(log_n + W)
-    circ = pr.build_circuit(rng, log_n, W)
-    beta = [int(v) for v in rand_field(rng, 2)]
-    gamma = [int(v) for v in rand_field(rng, 2)]
-    alpha = [int(v) for v in rand_field(rng, 2)]
+def _emu_quotient(emu, oracle, circ, beta, gamma, alpha, rb=3):
+    """(got, want): the product's K7 body under emulation vs the Python restatement, on oracle-made LDEs"""
+    log_n, W, R = circ["log_n"], circ["W"], circ["R"]
     zs = pr.ref_zs(circ, beta, gamma)
     L = {}
     for name, vals in (("consts", circ["consts"]), ("sigmas", circ["sigmas"]), ("wires", circ["wires"]), ("zs", zs)):
         L[name], _ = lde_bitrev(oracle, vals, log_n, rb)
     want = pr.ref_quotient(circ, {k: [[int(x) for x in r] for r in v] for k, v in L.items()}, beta, gamma, alpha, rb)
-    N = 1 << (log_n + rb)
+    n, N = 1 << log_n, 1 << (log_n + rb)
+    pi = None
+    if circ["n_public"]:
+        pv = np.zeros((1, n), dtype=np.uint64)
+        pv[0, :circ["n_public"]] = circ["public"]
+        pi, _ = lde_bitrev(oracle, pv, log_n, rb)
+    pos = np.concatenate([np.array(a, dtype=np.uint64) for a in circ["pos_consts"]]) if circ["flags"] else None
     got = np.zeros((2, N), dtype=np.uint64)
     arr = lambda v: np.array(v, dtype=np.uint64)
-    assert emu.emu_plonk_quotient(ptr(L["consts"]), ptr(L["sigmas"]), ptr(L["wires"]), ptr(L["zs"]), log_n, rb, W, ptr(arr(beta)),
-                                  ptr(arr(gamma)), ptr(arr(alpha)), ptr(got)) == 0
-    assert [[int(v) for v in r] for r in got] == want
-    # the quotient is a genuine polynomial: un-bit-reverse, inverse NTT, unshift -> degree < 8n,
-    # and (because the constraints hold on the trace domain) its top coefficients vanish too
+    assert emu.emu_plonk_quotient(ptr(L["consts"]), ptr(L["sigmas"]), ptr(L["wires"]), ptr(L["zs"]), ptr(pi) if pi is not None else None, log_n, rb,
+                                  W, R, circ["flags"], ptr(pos) if pos is not None else None, ptr(arr(beta)), ptr(arr(gamma)), ptr(arr(alpha)),
+                                  ptr(got)) == 0
+    return got, want
+
+
+def _assert_polynomial_quotient(emu, oracle, got, log_n, rb=3):
+    """the quotient is a genuine polynomial: un-bit-reverse, inverse NTT, unshift -> degree < 8n, and (because the
+    constraints hold on the trace domain) its top coefficients vanish too"""
     nat = np.zeros_like(got)
     sinv = pow(7, P - 2, P)
     assert emu.emu_bitrev_scale(ptr(got), ptr(nat), log_n + rb, 2, 1) == 0
@@ -74,9 +79,94 @@ def test_quotient_on_lde_domain(emu, oracle, log_n, W):
     for t in range(2):
         assert any(co[t]), "quotient should not be identically zero"
         assert not any(co[t][8 * n - 8:]), "degree bound 8n - 9 violated"
+    return sinv
+
+
+@pytest.mark.parametrize("log_n,W", [(3, 8), (4, 16)])
+def test_quotient_on_lde_domain(emu, oracle, log_n, W):
+    rb = 3
+    rng = np.random.default_rng(log_n + W)
+    circ = pr.build_circuit(rng, log_n, W)
+    beta = [int(v) for v in rand_field(rng, 2)]
+    gamma = [int(v) for v in rand_field(rng, 2)]
+    alpha = [int(v) for v in rand_field(rng, 2)]
+    got, want = _emu_quotient(emu, oracle, circ, beta, gamma, alpha, rb)
+    assert [[int(v) for v in r] for r in got] == want
+    sinv = _assert_polynomial_quotient(emu, oracle, got, log_n, rb)
+    N = 1 << (log_n + rb)
     # and the scaled variant of the same kernel
     nat2 = np.zeros_like(got)
     assert emu.emu_bitrev_scale(ptr(got), ptr(nat2), log_n + rb, 2, sinv) == 0
     for t in range(2):
         for i in (0, 1, 5, N - 1):
             assert int(nat2[t][i]) == int(got[t][fv.rev(i, log_n + rb)]) * pow(sinv, i, P) % P
+
+
+def test_poseidon_row_is_the_permutation(emu, oracle):
+    """the Poseidon row's witness: the Python restatement, the product's fill kernel (emulated) and the oracle's permutation agree,
+    and a filled row satisfies all 118 constraints while a corrupted one does not"""
+    consts = poseidon_consts("small")
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    ic = pr.int_consts(consts)
+    rng = np.random.default_rng(12)
+    log_n, W = 3, 136
+    n = 1 << log_n
+    wires = rand_field(rng, (W, n))
+    wires[:12, 0] = 0
+    wires[:12, 1] = P - 1
+    rows = np.array([0, 1, 3, 6], dtype=np.uint32)
+    before = wires.copy()
+    flat = np.concatenate([np.array(a, dtype=np.uint64) for a in consts])
+    assert emu.emu_poseidon_gate_fill_rows(ptr(wires), log_n, rows.ctypes.data, len(rows), ptr(flat)) == 0
+    for r in range(n):
+        if r not in rows:
+            assert np.array_equal(wires[:, r], before[:, r])
+            continue
+        row = pr.poseidon_row([int(v) for v in before[:12, r]], ic)
+        assert [int(v) for v in wires[:pr.POS_WIRES, r]] == row
+        st = before[:12, r].copy()
+        oracle.orc_poseidon_permute(ptr(st))
+        assert [int(v) for v in st] == row[12:24]
+        assert not any(pr.poseidon_constraints(pr.Base, row, ic))
+        assert np.array_equal(wires[pr.POS_WIRES:, r], before[pr.POS_WIRES:, r])
+        for j in (0, 12, 24, 60, 61, 82, 129):
+            bad = list(row)
+            bad[j] = (bad[j] + 1) % P
+            assert any(pr.poseidon_constraints(pr.Base, bad, ic)), f"wire {j} is not constrained"
+
+
+@pytest.mark.parametrize("log_n,W,R,n_public,pos_rows", [(3, 16, 8, 2, ()), (4, 24, 16, 5, ()), (3, 136, 80, 3, (1, 4, 5)), (4, 136, 24, 0, (0, 15))])
+def test_quotient_with_public_inputs_advice_wires_and_poseidon_rows(emu, oracle, log_n, W, R, n_public, pos_rows):
+    """the extended gate set under emulation: constant term c2, advice (unrouted) wires, public-input rows and Poseidon rows —
+    K6 over the routed wires and K7 against the Python restatements, and the quotient is a polynomial of degree < 8n"""
+    consts = poseidon_consts("small")
+    rng = np.random.default_rng(1000 * log_n + W + n_public)
+    circ = pr.build_circuit(rng, log_n, W, n_routed=R, n_public=n_public, poseidon_rows=pos_rows, consts=consts)
+    beta = [int(v) for v in rand_field(rng, 2)]
+    gamma = [int(v) for v in rand_field(rng, 2)]
+    alpha = [int(v) for v in rand_field(rng, 2)]
+    want_zs = pr.ref_zs(circ, beta, gamma)
+    got_zs = np.zeros_like(want_zs)
+    b, g = np.array(beta, dtype=np.uint64), np.array(gamma, dtype=np.uint64)
+    routed = np.ascontiguousarray(circ["wires"][:R])
+    assert emu.emu_plonk_zs(ptr(routed), ptr(circ["sigmas"]), log_n, R, ptr(b), ptr(g), ptr(got_zs)) == 0
+    assert np.array_equal(got_zs, want_zs)
+    got, want = _emu_quotient(emu, oracle, circ, beta, gamma, alpha)
+    assert [[int(v) for v in r] for r in got] == want
+    _assert_polynomial_quotient(emu, oracle, got, log_n)
+    # a wrong public input, a broken gate output and a corrupted Poseidon wire each make the quotient a non-polynomial
+    def broken(mut):
+        c2 = dict(circ)
+        c2["wires"] = circ["wires"].copy()
+        c2["public"] = list(circ["public"])
+        mut(c2)
+        g2, w2 = _emu_quotient(emu, oracle, c2, beta, gamma, alpha)
+        assert [[int(v) for v in r] for r in g2] == w2
+        with pytest.raises(AssertionError):
+            _assert_polynomial_quotient(emu, oracle, g2, log_n)
+    if n_public:
+        broken(lambda c: c["public"].__setitem__(n_public - 1, (c["public"][n_public - 1] + 1) % P))
+    if pos_rows:
+        def corrupt(c):
+            c["wires"][100, pos_rows[0]] ^= np.uint64(1)            # an advice wire of a Poseidon row (no copy constraint)
+        broken(corrupt)

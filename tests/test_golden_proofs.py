@@ -135,6 +135,35 @@ def test_forged_rate1_proof_is_rejected(pkg, oracle):
         assert not ok and "rate" in why, (mq, mp, mr, why)
 
 
+def test_host_verifier_gates_proof_statement_binding(pkg, oracle, golden):
+    """the golden proof of a circuit with public inputs, advice wires and Poseidon rows: accepted only for ITS statement"""
+    consts = poseidon_consts("small")
+    g = golden["gates"]
+    proof, cap, pub = bytes.fromhex(g["proof"]), np.array(g["circuit_cap"], dtype=np.uint64), g["public"]
+    q, pw = g["queries"], g["pow_bits"]
+    assert pkg.proof_public_inputs(proof) == pub
+    assert pkg.plonk_verify_host(consts, proof, cap, q, pw, public=pub) == (True, None)
+    assert pkg.plonk_verify_host(consts, proof, cap, q, pw, public=pkg.UNBOUND) == (True, None)
+    ok, why = pkg.plonk_verify_host(consts, proof, cap, q, pw, public=[pub[0], (pub[1] + 1) % (2**64 - 2**32 + 1)])
+    assert not ok and "public inputs" in why
+    ok, why = pkg.plonk_verify_host(consts, proof, cap, q, pw)                   # "no public inputs" is another statement
+    assert not ok and "public inputs" in why
+    words = np.frombuffer(proof, dtype="<u8")
+    for t in range(0, len(words), 11):
+        bad = words.copy()
+        bad[t] ^= np.uint64(1 << (t % 63))
+        assert not pkg.plonk_verify_host(consts, bad.tobytes(), cap, 1, 0, public=pkg.UNBOUND)[0], f"word {t}"
+    # the Poseidon rows are about THESE constants: with others the identity at zeta fails (and the transcript diverges)
+    assert not pkg.plonk_verify_host(poseidon_consts("medium"), proof, cap, q, pw, public=pub)[0]
+    # independent Python verifier
+    rc, circ, diag = consts
+    oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
+    info = pref.verify_plonk(proof, oracle, pos_consts=consts, public=pub)
+    assert (info["W"], info["R"], info["flags"]) == (g["W"], g["R"], pref.FLAG_POSEIDON)
+    with pytest.raises(fv.VerifyError):
+        pref.verify_plonk(proof, oracle, pos_consts=consts, public=[pub[1], pub[0]])
+
+
 def test_python_verifiers_accept_golden(oracle, golden):
     rc, circ, diag = poseidon_consts("small")
     oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
@@ -153,6 +182,8 @@ def test_gpu_prover_reproduces_golden_bytes(pkg, prover, golden):
     out = gen_proofs.make(pkg, prover)
     assert out["plonk"]["circuit_cap"] == golden["plonk"]["circuit_cap"]
     assert out["plonk"]["proof"] == golden["plonk"]["proof"]
+    assert out["gates"]["circuit_cap"] == golden["gates"]["circuit_cap"] and out["gates"]["public"] == golden["gates"]["public"]
+    assert out["gates"]["proof"] == golden["gates"]["proof"]
     assert out["fri"]["proof"] == golden["fri"]["proof"]
     # and the device-ctx verifier agrees with the host one
     rc, circ, diag = poseidon_consts("small")
