@@ -180,6 +180,8 @@ def load_library():
                                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]),
         "glp_plonk_proof_public_inputs": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, ctypes.POINTER(ctypes.c_size_t)]),
         "glp_poseidon_gate_fill_rows": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint32]),
+        "glp_plonk_proof_digest": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
+        "glp_plonk_proof_digest_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
         "glp_comm_unique_id": (ctypes.c_int, [_vp]),
         "glp_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
         "glp_comm_rank": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
@@ -259,6 +261,17 @@ def plonk_verify_host(constants, proof, circuit_cap, min_queries=DEFAULT_MIN_QUE
     pp, pn, keep = _public_arg(public)
     extra = (cap.ctypes.data if cap is not None else None, cap.size if cap is not None else 0, pp, pn)
     return _host_verify("glp_plonk_verify_host_ex", constants, proof, extra, min_queries, min_pow_bits)
+
+
+def proof_digest_host(constants, proof):
+    """Prover.proof_digest without a GPU or a ctx"""
+    lib = load_library()
+    rc, circ, diag = (np.ascontiguousarray(a, dtype=np.uint64) for a in constants)
+    words = np.frombuffer(bytes(proof), dtype="<u8").copy()
+    out = np.zeros(4, dtype=np.uint64)
+    if lib.glp_plonk_proof_digest_host(rc.ctypes.data, circ.ctypes.data, diag.ctypes.data, words.ctypes.data, words.nbytes, out.ctypes.data) != 0:
+        raise GlpError("not a circuit proof of this format")
+    return [int(v) for v in out]
 
 
 def proof_public_inputs(proof):
@@ -686,6 +699,13 @@ class Prover:
                             lambda p, n: self.lib.glp_plonk_verify_ex(self.ctx, p, n, cap.ctypes.data if cap is not None else None,
                                                                       cap.size if cap is not None else 0, pp, pn, min_queries, min_pow_bits),
                             proof)
+
+    def proof_digest(self, proof):
+        """4-word digest of a circuit proof's statement and commitments (glp_plonk_proof_digest): the aggregation tree's leaf"""
+        words = np.frombuffer(bytes(proof), dtype="<u8").copy()
+        out = np.zeros(4, dtype=np.uint64)
+        self._chk(self.lib.glp_plonk_proof_digest(self.ctx, words.ctypes.data, words.nbytes, out.ctypes.data), "glp_plonk_proof_digest")
+        return [int(v) for v in out]
 
     def poseidon_gate_fill_rows(self, d_wires, log_n, n_wires, rows):
         """witness generation for Poseidon rows: wires 12..129 of every listed row from its wires 0..11, in place on the device"""

@@ -410,7 +410,7 @@ extern "C" int glp_plonk_prove_ex(glp_ctx* c, glp_plonk_circuit* ck, const uint6
     // ---- openings: everything at zeta, the Z batch also at g*zeta --------------------------------
     glp_fri_config fc;
     memset(&fc, 0, sizeof(fc));
-    fc.log_n = log_n; fc.rate_bits = rb; fc.cap_height = ck->cap_h; fc.arity_bits = 4; fc.final_poly_bits = 5;
+    fc.log_n = log_n; fc.rate_bits = rb; fc.cap_height = ck->cap_h; fc.arity_bits = 4; fc.final_poly_bits = log_n < 5 ? log_n : 5;
     fc.num_queries = num_queries; fc.pow_bits = pow_bits; fc.shift = ck->shift;
     fc.n_points = 2; fc.point_mult[0] = 1; fc.point_mult[1] = gl_root_of_unity(log_n);
     glp_fri_batch fb[4];

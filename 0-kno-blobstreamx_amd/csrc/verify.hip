@@ -548,6 +548,42 @@ extern "C" int glp_plonk_verify(glp_ctx* c, const uint8_t* proof, size_t len, co
                                 uint32_t min_queries, uint32_t min_pow_bits) {
     return glp_plonk_verify_ex(c, proof, len, h_circuit_cap, cap_words, nullptr, 0, min_queries, min_pow_bits);
 }
+// digest of a circuit proof's STATEMENT AND COMMITMENTS: hash_no_pad(header (8) || public inputs || the four caps).  The caps bind every
+// committed polynomial, so two proofs with equal digests are proofs about the same circuit, inputs and witness commitment; this is the
+// leaf value of the Reduce step's aggregation tree (recursion.py).  No verification.
+static int proof_digest(const Hasher& h, const uint8_t* proof, size_t len, uint64_t* out4) {
+    const u64* w = (const u64*)proof;
+    const size_t nw = len / 8;
+    if (nw < 8 || w[0] != PLONK_TAG || w[1] > 24 || w[4] != 3 || w[5] > 12 || w[6] > (1ull << 24)) return GLP_E_INVALID;
+    const u32 log_N = (u32)(w[1] + w[4]);
+    const size_t capw = (size_t)4 << (w[5] < log_N ? w[5] : log_N);
+    const size_t total = 8 + (size_t)w[6] + 4 * capw;
+    if (total > nw) return GLP_E_INVALID;
+    std::vector<u64> buf(total);
+    for (size_t i = 0; i < total; i++) buf[i] = w[i] % GL_P;
+    u64 d[4];
+    h.hash_or_noop(buf.data(), total, d);
+    memcpy(out4, d, 32);
+    return GLP_OK;
+}
+extern "C" int glp_plonk_proof_digest(glp_ctx* c, const uint8_t* proof, size_t len, uint64_t* h_out4) {
+    if (!c) return GLP_E_INVALID;
+    if (!proof_args_ok(proof, len) || !h_out4) { glp_set_err(c, "glp_plonk_proof_digest: bad argument"); return GLP_E_INVALID; }
+    Hasher h;
+    glp_challenger ch;
+    if (!make_hasher(c, h, ch)) return GLP_E_STATE;
+    const int rc = proof_digest(h, proof, len, h_out4);
+    if (rc) glp_set_err(c, "glp_plonk_proof_digest: not a circuit proof of this format");
+    return rc;
+}
+extern "C" int glp_plonk_proof_digest_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* proof, size_t len,
+                                           uint64_t* h_out4) {
+    Hasher h;
+    glp_challenger ch;
+    if (!proof_args_ok(proof, len) || !h_out4 || !make_hasher_from(h_rc, h_mds_circ, h_mds_diag, h, ch)) return GLP_E_INVALID;
+    return proof_digest(h, proof, len, h_out4);
+}
+
 extern "C" int glp_plonk_proof_public_inputs(const uint8_t* proof, size_t len, uint64_t* h_out, size_t* n_words) {
     if (!proof_args_ok(proof, len) || !n_words || (!h_out && *n_words)) return GLP_E_INVALID;
     const u64* w = (const u64*)proof;

@@ -158,3 +158,33 @@ def reduce_verify(verify_leaf, proofs, device=None, comm=None):
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = int(t.item())
     return bool(ok)
+
+
+ZERO_DIGEST = [0, 0, 0, 0]      # pads the leaf list to a power of two in the aggregation tree
+
+
+def reduce_aggregate(prover, verify_leaf, proofs, device=None, comm=None, num_queries=28, pow_bits=16):
+    """The Reduce step with its first in-circuit part (recursion.py).  (1) every gathered leaf proof is verified natively, split
+    across ranks, verdicts all-reduced (``reduce_verify``: host arithmetic — the part that is NOT in-circuit yet);
+    (2) rank 0 hashes each leaf proof to its 4-word digest (statement + commitments) and PROVES, on the GPU, the binary Poseidon
+    tree over the digests: one succinct proof whose public inputs are the digests and the root.  Returns a dict: ``ok`` (every leaf
+    verifies), and on rank 0 ``root_proof``, ``root``, ``digests``, ``key`` (the aggregation circuit's verifying key)."""
+    import importlib
+    rank, _ = _world(comm)
+    ok = reduce_verify(verify_leaf, proofs, device=device, comm=comm)
+    out = {"ok": ok}
+    if rank == 0 and ok:
+        rec = importlib.import_module(__package__ + ".recursion")
+        digests = [prover.proof_digest(p) for p in proofs]
+        size = 1 << max(1, (len(digests) - 1).bit_length())
+        digests += [ZERO_DIGEST] * (size - len(digests))
+        root_proof, root, key = rec.aggregate(prover, digests, num_queries, pow_bits)
+        out.update(root_proof=root_proof, root=root, digests=digests, key=key)
+    return out
+
+
+def verify_aggregate(prover, root_proof, key, digests, root, min_queries=28, min_pow_bits=16):
+    """the consumer of a Reduce: the root proof is about exactly these leaf digests and this root, for the n-leaf aggregation
+    circuit ``key`` (recursion.aggregation_key).  The leaf proofs behind the digests are checked by whoever holds them."""
+    public = [int(v) for d in digests for v in d] + [int(v) for v in root]
+    return prover.plonk_verify(root_proof, key, min_queries, min_pow_bits, public=public)

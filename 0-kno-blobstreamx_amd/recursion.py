@@ -1,0 +1,236 @@
+"""Circuits over the build-defined gate set (include/glprover.h: arithmetic/constant gates, public inputs, Poseidon rows, copy
+constraints) and the first in-circuit pieces of the MapReduce Reduce step (upstream names
+recalled, unverified — reference file:line NONE, the mount is empty: plonky2x ``CircuitBuilder``, plonky2
+``CircuitBuilder::{mul_add, constant, connect, hash_n_to_hash_no_pad, verify_merkle_proof_to_cap}``).
+
+``CircuitBuilder`` is the host-side ``define`` surface: variables, gates, copy constraints, public inputs; ``build`` lays the
+gates out in rows (a row's constants are shared by its 20 gate slots, so rows are typed by their constants), derives sigma and
+the witness matrix, and returns a ``PlonkCircuit`` ready to prove on the GPU.  Poseidon rows carry only their 12 inputs and 12
+outputs as variables; their 106 S-box-input wires are filled on the device (``glp_poseidon_gate_fill_rows``).
+
+What is in-circuit here, and what is not: the AGGREGATION of the leaf proofs — a Poseidon Merkle tree over the
+leaf-proof digests, every two-to-one hash a constrained Poseidon row — and Merkle-path verification to a cap (conditional swaps
+by arithmetic gates).  The leaf proofs themselves are still verified natively (host arithmetic): an in-circuit FRI verifier
+needs extension-field arithmetic gadgets and the transcript in-circuit, listed in DESIGN.md.
+"""
+import numpy as np
+
+from . import CIRCUIT_POSEIDON_GATE, P, PLONK_NCONST, POS_GATE_WIRES, PlonkCircuit  # noqa: F401
+
+
+class CircuitBuilder:
+    """variables are integer handles; every gate is added with its witness value computed on the spot (big-int arithmetic)"""
+
+    def __init__(self, prover, n_wires=136, n_routed=80):
+        assert n_routed % 8 == 0 and n_wires % 8 == 0 and 24 <= n_routed <= n_wires and n_wires >= POS_GATE_WIRES
+        self.prover, self.W, self.R = prover, n_wires, n_routed
+        self.G = n_routed // 4
+        self.values = []                 # variable -> value
+        self.parent = []                 # union-find over variables (copy constraints)
+        self.arith_rows = {}             # (c0, c1, c2) -> list of rows, a row = list of (x, y, z, w) variable tuples
+        self.pos_rows = []               # (in vars[12], out vars[12])
+        self.public = []
+        self._consts = {}
+
+    # ---- variables and copy constraints ---------------------------------------------------------------------------------------
+    def var(self, value):
+        self.values.append(int(value) % P)
+        self.parent.append(len(self.parent))
+        return len(self.values) - 1
+
+    def _find(self, a):
+        while self.parent[a] != a:
+            self.parent[a] = self.parent[self.parent[a]]
+            a = self.parent[a]
+        return a
+
+    def assert_equal(self, a, b):
+        """copy constraint: a and b are the same wire value (enforced by the permutation argument)"""
+        if self.values[a] != self.values[b]:
+            raise ValueError("assert_equal on different values: the witness does not satisfy the circuit")
+        ra, rb = self._find(a), self._find(b)
+        if ra != rb:
+            self.parent[ra] = rb
+
+    def value(self, v):
+        return self.values[v]
+
+    # ---- gates ----------------------------------------------------------------------------------------------------------------
+    def arith(self, c0, c1, c2, x, y, z):
+        """w = c0*x*y + c1*z + c2 (one slot of a row whose constants are (c0, c1, c2))"""
+        key = (int(c0) % P, int(c1) % P, int(c2) % P)
+        w = self.var(key[0] * self.values[x] * self.values[y] + key[1] * self.values[z] + key[2])
+        rows = self.arith_rows.setdefault(key, [[]])
+        if len(rows[-1]) == self.G:
+            rows.append([])
+        rows[-1].append((x, y, z, w))
+        return w
+
+    def constant(self, k):
+        k = int(k) % P
+        if k not in self._consts:
+            d = self.var(0)
+            self._consts[k] = self.arith(0, 0, k, d, d, d)
+        return self._consts[k]
+
+    def mul(self, x, y):
+        return self.arith(1, 0, 0, x, y, x)
+
+    def add(self, x, y):
+        return self.arith(1, 1, 0, x, self.constant(1), y)
+
+    def sub(self, x, y):
+        return self.arith(1, P - 1, 0, x, self.constant(1), y)
+
+    def assert_bool(self, b):
+        self.assert_equal(self.arith(1, P - 1, 0, b, b, b), self.constant(0))        # b*b - b = 0
+
+    def select(self, b, t, f):
+        """b ? t : f for a boolean b:  f + b*(t - f)"""
+        return self.arith(1, 1, 0, b, self.sub(t, f), f)
+
+    def public_input(self, v):
+        self.public.append(v)
+
+    def poseidon(self, ins):
+        """one permutation row; ins: 12 variables -> 12 output variables (values from the GPU's own permutation)"""
+        assert len(ins) == 12
+        out = self.prover.poseidon_permute(np.array([[self.values[v] for v in ins]], dtype=np.uint64))[0]
+        outs = [self.var(int(v)) for v in out]
+        self.pos_rows.append((list(ins), outs))
+        return outs
+
+    def two_to_one(self, left4, right4):
+        """PoseidonHash::two_to_one: permute(left || right || 0 0 0 0)[0..4)"""
+        zero = self.constant(0)
+        return self.poseidon(list(left4) + list(right4) + [zero] * 4)[:4]
+
+    def hash_no_pad(self, elems):
+        """overwrite-mode sponge, rate 8 (the leaf hashing of the Merkle trees); <= 4 elements: the padded input itself"""
+        zero = self.constant(0)
+        if len(elems) <= 4:
+            return list(elems) + [zero] * (4 - len(elems))
+        state = [zero] * 12
+        for off in range(0, len(elems), 8):
+            chunk = list(elems[off:off + 8])
+            state = self.poseidon(chunk + state[len(chunk):])
+        return state[:4]
+
+    def merkle_root_from_path(self, leaf_digest4, index_bits, siblings):
+        """verify_merkle_proof: fold a digest up a path.  index_bits[l] (boolean variables, LSB first) says whether the node is the
+        RIGHT child at level l; siblings[l] = 4 variables.  Returns the 4 variables of the node reached (compare with a cap entry)."""
+        cur = list(leaf_digest4)
+        for b, sib in zip(index_bits, siblings):
+            self.assert_bool(b)
+            left = [self.select(b, s, c) for c, s in zip(cur, sib)]
+            right = [self.select(b, c, s) for c, s in zip(cur, sib)]
+            cur = self.two_to_one(left, right)
+        return cur
+
+    # ---- layout ---------------------------------------------------------------------------------------------------------------
+    def build(self, cap_height=1):
+        """rows: [public inputs][Poseidon rows][arithmetic rows by constants], padded to a power of two.
+        Returns (PlonkCircuit, device wires buffer with the Poseidon rows filled, public values)."""
+        W, R, G = self.W, self.R, self.G
+        arith = [(key, row) for key, rows in sorted(self.arith_rows.items()) for row in rows if row]
+        n_rows = len(self.public) + len(self.pos_rows) + len(arith)
+        log_n = max(3, (max(n_rows, 1) - 1).bit_length())
+        n = 1 << log_n
+        consts = np.zeros((PLONK_NCONST, n), dtype=np.uint64)
+        wires = np.zeros((W, n), dtype=np.uint64)
+        cells = {}                                   # class root -> [(wire, row)]
+
+        def place(v, j, i):
+            wires[j, i] = self.values[v]
+            cells.setdefault(self._find(v), []).append((j, i))
+
+        i = 0
+        for v in self.public:
+            consts[4, i] = 1
+            place(v, 0, i)
+            i += 1
+        pos_row_ids = []
+        for ins, outs in self.pos_rows:
+            consts[5, i] = 1
+            for j, v in enumerate(ins):
+                place(v, j, i)
+            for j, v in enumerate(outs):
+                place(v, 12 + j, i)
+            pos_row_ids.append(i)
+            i += 1
+        for (c0, c1, c2), row in arith:
+            consts[0, i], consts[1, i], consts[2, i], consts[3, i] = 1, c0, c1, c2
+            for g in range(G):
+                if g < len(row):
+                    for k, v in enumerate(row[g]):
+                        place(v, 4 * g + k, i)
+                else:
+                    wires[4 * g + 3, i] = c2                         # an unused slot must still satisfy its gate: w = c2
+            i += 1
+        # sigma: identity, then one cycle per copy class
+        ks = [pow(7, j, P) for j in range(R)]
+        w = pow(7, (P - 1) >> log_n, P)
+        wp = [1] * n
+        for r in range(1, n):
+            wp[r] = wp[r - 1] * w % P
+        sigma = np.array([[ks[j] * wp[r] % P for r in range(n)] for j in range(R)], dtype=np.uint64)
+        for members in cells.values():
+            if any(j >= R for j, _ in members):
+                raise ValueError("a variable sits on an unrouted wire")
+            for a, (j, r) in enumerate(members):
+                jj, rr = members[(a + 1) % len(members)]
+                sigma[j, r] = ks[jj] * wp[rr] % P
+        ck = PlonkCircuit(self.prover, consts, sigma, cap_height=cap_height, n_wires=W, n_public=len(self.public), poseidon=True)
+        dw = self.prover.to_device(wires)
+        self.prover.poseidon_gate_fill_rows(dw, log_n, W, pos_row_ids)               # the 106 S-box-input wires per row, on the GPU
+        return ck, dw, [self.values[v] for v in self.public]
+
+
+# ---- the Reduce step's aggregation tree -----------------------------------------------------------------------------------------
+def merkle_root_host(prover, digests):
+    """Poseidon Merkle root (two_to_one) of a power-of-two list of 4-word digests, on the GPU permutation (level by level)"""
+    level = [list(map(int, d)) for d in digests]
+    assert len(level) & (len(level) - 1) == 0 and level
+    while len(level) > 1:
+        st = np.array([level[2 * k] + level[2 * k + 1] + [0, 0, 0, 0] for k in range(len(level) // 2)], dtype=np.uint64)
+        level = [[int(v) for v in row[:4]] for row in prover.poseidon_permute(st)]
+    return level[0]
+
+
+def build_aggregation_circuit(prover, digests):
+    """The circuit of one Reduce: public inputs = the leaf-proof digests (4 words each, leaf order) then the root (4 words);
+    constraints = every node of the binary Poseidon tree over them.  Returns (circuit, device wires, public values)."""
+    n = len(digests)
+    assert n >= 2 and n & (n - 1) == 0, "a power-of-two number of leaves (pad with a fixed digest)"
+    b = CircuitBuilder(prover)
+    level = []
+    for d in digests:
+        vs = [b.var(int(x)) for x in d]
+        for v in vs:
+            b.public_input(v)
+        level.append(vs)
+    while len(level) > 1:
+        level = [b.two_to_one(level[2 * k], level[2 * k + 1]) for k in range(len(level) // 2)]
+    for v in level[0]:
+        b.public_input(v)
+    return b.build()
+
+
+def aggregate(prover, digests, num_queries=28, pow_bits=16):
+    """prove the aggregation tree: returns (root proof bytes, root digest, circuit cap) — the succinct object a Reduce hands on"""
+    ck, dw, public = build_aggregation_circuit(prover, digests)
+    try:
+        proof = ck.prove_(dw, num_queries, pow_bits, public=public)
+        return proof, public[-4:], ck.cap()
+    finally:
+        dw.free()
+        ck.free()
+
+
+def aggregation_key(prover, n_leaves):
+    """the verifying key (circuit cap) of the n-leaf aggregation circuit: it depends on n only, not on the digests"""
+    ck, dw, _ = build_aggregation_circuit(prover, [[0, 0, 0, 0]] * n_leaves)
+    cap = ck.cap()
+    dw.free()
+    ck.free()
+    return cap

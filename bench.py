@@ -429,6 +429,26 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
     t1 = time.perf_counter()
     all_ok = mr.reduce_verify(verifiers, proofs, device=dev)
     dt_red = time.perf_counter() - t1
+    # ... and its first in-circuit part: ONE root proof, on rank 0's GPU, of the Poseidon tree over the leaf-proof digests
+    agg = None
+    if rank == 0 and all_ok:
+        try:
+            rec = importlib.import_module(graft.PKG_NAME + ".recursion")
+            t2 = time.perf_counter()
+            digests = [provers[0].proof_digest(p) for p in proofs]
+            digests += [mr.ZERO_DIGEST] * ((1 << max(1, (len(digests) - 1).bit_length())) - len(digests))
+            ckr, dwr, public = rec.build_aggregation_circuit(provers[0], digests)
+            t3 = time.perf_counter()
+            root_proof = ckr.prove_(dwr, 28, 16, public=public)
+            t4 = time.perf_counter()
+            root_ok = bool(mr.verify_aggregate(provers[0], root_proof, ckr.cap(), digests, public[-4:]))
+            agg = {"reduce_proof_seconds": round(t4 - t2, 4), "build_circuit_seconds": round(t3 - t2, 4), "prove_seconds": round(t4 - t3, 4),
+                   "root_proof_bytes": len(root_proof), "root_proof_verifies": root_ok, "rows": 1 << ckr.log_n, "wires": ckr.n_wires,
+                   "poseidon_rows": len(digests) - 1, "public_inputs": len(public)}
+            dwr.free()
+            ckr.free()
+        except Exception as e:  # noqa: BLE001
+            agg = {"error": f"{type(e).__name__}: {e}"[:200]}
     if world > 1:
         tt = torch.tensor([dt, dt_red], dtype=torch.float64, device=_coll_device())
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -436,10 +456,12 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
     res = {"stage": "mapreduce", "n_leaves": n_leaves, "leaves_per_gpu": leaves_per_rank, "leaf_log_n": log_n,
            "leaf_wires": W, "n_gpus": world, "provers_per_gpu": provers_per_gpu, "seconds": round(dt, 4),
            "leaf_proofs_per_s": round(n_leaves / dt, 1), "reduce_verify_seconds": round(dt_red, 4), "all_leaves_verify": all_ok,
-           "leaf_proof_bytes": len(proofs[0]), "all_present": all(len(p) > 0 for p in proofs), "c_abi_exchange": abi,
+           "leaf_proof_bytes": len(proofs[0]), "all_present": all(len(p) > 0 for p in proofs), "c_abi_exchange": abi, "aggregation": agg,
            "note": "BASELINE configs[2]/[3] shape with the build-defined leaf circuit (NOT upstream's); seconds = Map + one "
                    "all-gather of padded proofs; Reduce = native verification of every leaf (host arithmetic, split across "
-                   "ranks and host threads) + all-reduce of the verdicts, NOT a recursive proof"}
+                   "ranks and host threads) + all-reduce of the verdicts, then ONE root proof on rank 0 of the Poseidon Merkle tree over the "
+                   "leaf-proof digests (public inputs: digests + root; every two-to-one hash a constrained Poseidon row).  Still host-checked, "
+                   "not in-circuit: the verification of each leaf proof (no in-circuit FRI verifier yet)"}
     for d, c, q in zip(dws, cks, provers):
         d.free()
         c.free()

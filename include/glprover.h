@@ -272,6 +272,11 @@ int glp_plonk_verify_ex(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, 
 /* the public inputs a proof carries: copies min(*n_words, n_public) words to h_out (may be NULL with *n_words = 0) and stores
  * n_public in *n_words.  No verification: GLP_E_INVALID when the bytes are not a circuit proof of this format. */
 int glp_plonk_proof_public_inputs(const uint8_t* h_proof, size_t proof_len, uint64_t* h_out, size_t* n_words);
+/* 4-word Poseidon digest of a circuit proof's statement and commitments: hash_no_pad(header || public inputs || the four caps) —
+ * the leaf value of the Reduce step's aggregation tree (0-kno-blobstreamx_amd/recursion.py).  No verification. */
+int glp_plonk_proof_digest(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, uint64_t* h_out4);
+int glp_plonk_proof_digest_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
+                                size_t proof_len, uint64_t* h_out4);
 
 /* The same two verifiers for a host WITHOUT a GPU (a light client, CI): no ctx — the Poseidon constants are
  * passed explicitly (the arguments of glp_set_poseidon_constants: 360, 12, 12 words) and err (may be NULL)
