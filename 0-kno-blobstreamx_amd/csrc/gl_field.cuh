@@ -44,7 +44,13 @@ GL_HD void glp_static_for(F&& f) {
 // borrow kept in an SGPR lane mask it is 4 VALU + 1 SALU.  Measured issue costs are ~4.2 cycles
 // for every carry/64-bit/VOP3 op (profiles/r01_ubench_valu2.txt), so the instruction count is
 // the cost.  gfx940+ needs 2 wait states between a VALU writing an SGPR and a VALU reading it
-// (the compiler's hazard recogniser does not look inside inline asm): the s_nop's below.
+// (the compiler's hazard recogniser does not look inside inline asm) — EXCEPT through VCC, which
+// the hardware forwards (the compiler's own v_add_co/v_addc_co chains run back to back on it).
+// Round 2: every carry/borrow that a following VALU consumes therefore lives in VCC (declared
+// clobbered); an explicit SGPR pair only carries masks that the next consumer reads on the SALU
+// (s_andn2/s_or), which interlocks.  That removed ~9 s_nop per multiplication (measured: Merkle
+// commitment -2.3 %, proof -2.4 %, NTT +0.5 %; profiles/r02_ab_vcc_carry.txt) and is what
+// tests/test_isa_hazards.py checks in the emitted ISA.
 // s_andn2/s_or write SCC, which the compiler may hold live (s_add_u32/s_addc_u32 address
 // arithmetic): every block with a SALU op declares the "scc" clobber.
 // Host code and tests/emu use the portable forms (GLP_ASM_FIELD off).
@@ -83,17 +89,15 @@ GL_HD u64 gl_add(u64 a, u64 b) {
 GL_HD u64 gl_sub(u64 a, u64 b) {
 #if GLP_ASM_FIELD
     u32 dl, dh;
-    u64 B, K;
-    asm("v_sub_co_u32 %0, %2, %4, %6\n\t"
-        "s_nop 1\n\t"
-        "v_subb_co_u32 %1, %2, %5, %7, %2\n\t"          // B = borrow of a - b
-        "s_nop 1\n\t"
-        "v_addc_co_u32 %0, %3, 0, %0, %2\n\t"            // + p = (+1, -1 on the high word): lo += B, carry K
-        "s_andn2_b64 %2, %2, %3\n\t"
-        "v_subbrev_co_u32 %1, %3, 0, %1, %2"              // hi -= (B & ~K)
-        : "=&v"(dl), "=&v"(dh), "=&s"(B), "=&s"(K)
+    u64 K;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"         // B = borrow of a - b, in VCC (carry forwarding: no wait states)
+        "v_addc_co_u32 %0, %2, 0, %0, vcc\n\t"            // + p = (+1, -1 on the high word): lo += B, carry K
+        "s_andn2_b64 vcc, vcc, %2\n\t"
+        "v_subbrev_co_u32 %1, %2, 0, %1, vcc"              // hi -= (B & ~K)
+        : "=&v"(dl), "=&v"(dh), "=&s"(K)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
-        : "scc");
+        : "scc", "vcc");
     return gl_make64(dl, dh);
 #else
     u64 d = a - b;
@@ -106,29 +110,28 @@ GL_HD u64 gl_sub(u64 a, u64 b) {
 template <bool CANON>
 GL_HD u64 gl_mad_eps(u32 w, u64 t) {
 #if GLP_ASM_FIELD
-    u64 r, C;
+    u64 r;
     u32 m;
     if constexpr (CANON) {
-        u64 G;
-        asm("v_mad_u64_u32 %0, %1, %4, -1, %5\n\t"
-            "v_cmp_le_u64 %2, %6, %0\n\t"
-            "s_or_b64 %1, %1, %2\n\t"
+        u64 G, J;
+        asm("v_mad_u64_u32 %0, vcc, %4, -1, %5\n\t"
+            "v_cmp_le_u64 %1, %6, %0\n\t"
+            "s_or_b64 vcc, vcc, %1\n\t"
             "s_nop 0\n\t"
-            "v_cndmask_b32 %3, 0, -1, %1\n\t"
-            "v_mad_u64_u32 %0, %2, %3, 1, %0"              // r += m (m = eps or 0), as one op
-            : "=&v"(r), "=&s"(C), "=&s"(G), "=&v"(m)
+            "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+            "v_mad_u64_u32 %0, %3, %2, 1, %0"              // r += m (m = eps or 0), as one op
+            : "=&v"(r), "=&s"(G), "=&v"(m), "=&s"(J)
             : "v"(w), "v"(t), "s"(GL_P)
-            : "scc");
+            : "scc", "vcc");
     } else {
         u64 J;
-        asm("v_mad_u64_u32 %0, %1, %4, -1, %5\n\t"
-            "s_nop 1\n\t"
-            "v_cndmask_b32 %2, 0, -1, %1\n\t"
-            "v_mad_u64_u32 %0, %3, %2, 1, %0"
-            : "=&v"(r), "=&s"(C), "=&v"(m), "=&s"(J)
-            : "v"(w), "v"(t));
+        asm("v_mad_u64_u32 %0, vcc, %3, -1, %4\n\t"
+            "v_cndmask_b32 %1, 0, -1, vcc\n\t"
+            "v_mad_u64_u32 %0, %2, %1, 1, %0"
+            : "=&v"(r), "=&v"(m), "=&s"(J)
+            : "v"(w), "v"(t)
+            : "vcc");
     }
-    // wrapped: r <= 2^64 - 2^33, so + eps neither overflows nor reaches p; else r - p < 2^32
     return r;
 #else
     const u64 t1 = ((u64)w << 32) - w;
@@ -149,19 +152,16 @@ template <bool CANON>
 GL_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
     const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
 #if GLP_ASM_FIELD
-    // t0 = lo - h1 (+ p on borrow; the wrapped value is >= 2^64 - 2^32 so "- eps" cannot underflow)
     u32 tl, th;
-    u64 B, K;
-    asm("v_sub_co_u32 %0, %2, %4, %6\n\t"
-        "s_nop 1\n\t"
-        "v_subbrev_co_u32 %1, %2, 0, %5, %2\n\t"
-        "s_nop 1\n\t"
-        "v_addc_co_u32 %0, %3, 0, %0, %2\n\t"
-        "s_andn2_b64 %2, %2, %3\n\t"
-        "v_subbrev_co_u32 %1, %3, 0, %1, %2"
-        : "=&v"(tl), "=&v"(th), "=&s"(B), "=&s"(K)
+    u64 K;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32 %0, %2, 0, %0, vcc\n\t"
+        "s_andn2_b64 vcc, vcc, %2\n\t"
+        "v_subbrev_co_u32 %1, %2, 0, %1, vcc"
+        : "=&v"(tl), "=&v"(th), "=&s"(K)
         : "v"((u32)lo), "v"((u32)(lo >> 32)), "v"(h1)
-        : "scc");
+        : "scc", "vcc");
     return gl_mad_eps<CANON>(h0, gl_make64(tl, th));
 #else
     u64 t0;
@@ -198,16 +198,16 @@ GL_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 GL_HD u64 gl_fold_small(u64 al, u64 ah) {
 #if GLP_ASM_FIELD
     u32 lh, m;
-    u64 C1, C2, v;
+    u64 C1, J, v;
     asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(lh), "=s"(C1) : "v"((u32)(al >> 32)), "v"((u32)ah));
-    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
-        "s_or_b64 %1, %1, %5\n\t"
+    asm("v_mad_u64_u32 %0, vcc, %3, -1, %4\n\t"
+        "s_or_b64 vcc, vcc, %5\n\t"
         "s_nop 0\n\t"
-        "v_cndmask_b32 %2, 0, -1, %1\n\t"
-        "v_mad_u64_u32 %0, %1, %2, 1, %0"
-        : "=&v"(v), "=&s"(C2), "=&v"(m)
+        "v_cndmask_b32 %1, 0, -1, vcc\n\t"
+        "v_mad_u64_u32 %0, %2, %1, 1, %0"
+        : "=&v"(v), "=&v"(m), "=&s"(J)
         : "v"((u32)(ah >> 32)), "v"(gl_make64((u32)al, lh)), "s"(C1)
-        : "scc");
+        : "scc", "vcc");
     return v;
 #else
     const u64 l = al + (ah << 32);

@@ -1,0 +1,123 @@
+"""CPU-side guard for the hand-written gfx950 field arithmetic (VERDICT r1 "next" item 7; the GPU memory fault of round 1 came from
+an inline-asm block that clobbered SCC without saying so).  Two checks, no GPU needed (hipcc cross-compiles):
+
+ 1. source: every asm statement of gl_field.cuh that contains an SCC-writing SALU op (s_andn2 / s_or / s_and ...) declares the "scc"
+    clobber, and every one that names vcc declares "vcc" — the compiler keeps SCC/VCC live across address arithmetic otherwise;
+ 2. emitted ISA of a probe kernel using every primitive, and of the shipped NTT kernels: no VALU reads an SGPR (pair) that a VALU wrote
+    fewer than 2 wait states earlier (the gfx940+ rule the compiler's hazard recogniser cannot apply inside inline asm); VCC is exempt —
+    the hardware forwards it, and the compiler's own carry chains rely on that."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "0-kno-blobstreamx_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+SCC_WRITERS = ("s_andn2", "s_or_", "s_and_", "s_xor", "s_add", "s_sub", "s_cmp", "s_lshl", "s_lshr", "s_not", "s_bfe")
+
+
+def asm_statements(src):
+    """(template text, clobber text) of every asm(...) statement"""
+    out = []
+    for m in re.finditer(r"\basm\s*\(", src):
+        depth, i = 1, m.end()
+        while depth and i < len(src):
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        body = re.sub(r'("(?:[^"\\]|\\.)*")|//[^\n]*', lambda mm: mm.group(1) or "", src[m.end():i - 1])   # drop // comments
+        strings = re.findall(r'"((?:[^"\\]|\\.)*)"', body)
+        parts = re.split(r'(?<!:):(?!:)', re.sub(r'"(?:[^"\\]|\\.)*"', lambda s: s.group(0).replace(":", "\x00"), body))
+        clob = parts[3].replace("\x00", ":") if len(parts) > 3 else ""
+        n_template = len(re.findall(r'"((?:[^"\\]|\\.)*)"', parts[0]))
+        out.append((" ".join(strings[:n_template]), clob))
+    return out
+
+
+def test_asm_blocks_declare_scc_and_vcc():
+    src = open(os.path.join(CSRC, "gl_field.cuh")).read()
+    stmts = asm_statements(src)
+    assert len(stmts) >= 6
+    for text, clob in stmts:
+        if any(w in text for w in SCC_WRITERS):
+            assert '"scc"' in clob, f"asm block writes SCC without declaring it: {text[:80]}"
+        if re.search(r"\bvcc\b", text):
+            assert '"vcc"' in clob, f"asm block uses vcc without declaring it: {text[:80]}"
+
+
+SGPR = re.compile(r"^s\[(\d+):(\d+)\]$|^s(\d+)$")
+
+
+def sreg(op):
+    m = SGPR.match(op)
+    if not m:
+        return None
+    return (int(m.group(1)), int(m.group(2))) if m.group(1) else (int(m.group(3)), int(m.group(3)))
+
+
+def overlaps(a, b):
+    return a[0] <= b[1] and b[0] <= a[1]
+
+
+def valu_sgpr_hazards(asm_text):
+    """[(line number, writer, reader)] for every VALU that reads a non-VCC SGPR written by a VALU < 2 wait states before"""
+    pending = []          # (sgpr range, wait states since the write, writer text)
+    bad = []
+    for ln, line in enumerate(asm_text.splitlines(), 1):
+        t = line.split(";")[0].strip()
+        if not t or t.endswith(":") or t.startswith("."):
+            continue
+        parts = t.split(None, 1)
+        op = parts[0]
+        args = [a.strip() for a in parts[1].split(",")] if len(parts) > 1 else []
+        if op.startswith("v_"):
+            if op.startswith("v_cmp") and not op.endswith("_e32"):
+                dst_pos = [0]
+            elif "_co_" in op or op.startswith(("v_mad_u64_u32", "v_mad_i64_i32", "v_div_scale")):
+                dst_pos = [1]
+            else:
+                dst_pos = []
+            reads = [sreg(a) for k, a in enumerate(args) if k not in dst_pos and k > 0 and sreg(a)]
+            for rng, ws, wtxt in pending:
+                if ws < 2 and any(overlaps(rng, r) for r in reads):
+                    bad.append((ln, wtxt, t))
+            writes = [sreg(args[k]) for k in dst_pos if k < len(args) and sreg(args[k])]
+        else:
+            writes = []
+        step = (int(args[0], 0) + 1) if op == "s_nop" and args else 1
+        pending = [(r, ws + step, w) for r, ws, w in pending if ws + step < 2 and not (op.startswith("s_") and False)]
+        pending += [(w, 0, t) for w in writes]
+    return bad
+
+
+def device_asm(src, extra=()):
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "--cuda-device-only",
+                        "-S", src, "-o", "-"] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_hazard_checker_catches_a_planted_hazard():
+    bad = "v_add_co_u32 v1, s[10:11], v2, v3\n\tv_addc_co_u32 v4, s[12:13], v5, v6, s[10:11]\n"
+    assert len(valu_sgpr_hazards(bad)) == 1
+    ok1 = "v_add_co_u32 v1, s[10:11], v2, v3\n\ts_nop 1\n\tv_addc_co_u32 v4, s[12:13], v5, v6, s[10:11]\n"
+    ok2 = "v_add_co_u32 v1, vcc, v2, v3\n\tv_addc_co_u32 v4, vcc, v5, v6, vcc\n"
+    ok3 = "v_cmp_le_u64 s[12:13], s[6:7], v[6:7]\n\ts_or_b64 vcc, vcc, s[12:13]\n\tv_cndmask_b32 v1, 0, -1, vcc\n"
+    assert not valu_sgpr_hazards(ok1) and not valu_sgpr_hazards(ok2) and not valu_sgpr_hazards(ok3)
+    one_short = "v_mad_u64_u32 v[6:7], s[10:11], v22, -1, v[28:29]\n\ts_nop 0\n\tv_cndmask_b32 v1, 0, -1, s[10:11]\n"
+    assert len(valu_sgpr_hazards(one_short)) == 1
+
+
+def test_probe_kernel_has_no_valu_sgpr_hazard():
+    asm = device_asm(os.path.join(ROOT, "tests", "isa", "field_probe.hip"))
+    assert asm.count("#ASMSTART") >= 10, "the probe no longer instantiates the inline-asm primitives"
+    assert not valu_sgpr_hazards(asm), valu_sgpr_hazards(asm)[:5]
+
+
+@pytest.mark.parametrize("log_r", [8, 10])
+def test_shipped_ntt_kernels_have_no_valu_sgpr_hazard(log_r):
+    extra = ["-DGLP_INST_LOG_R=%d" % log_r] + (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if log_r == 10 else [])
+    asm = device_asm(os.path.join(CSRC, "ntt_inst.hip"), extra)
+    assert asm.count("#ASMSTART") > 100
+    assert not valu_sgpr_hazards(asm), valu_sgpr_hazards(asm)[:5]
