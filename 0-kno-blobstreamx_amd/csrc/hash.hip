@@ -140,12 +140,30 @@ static int merkle_impl(glp_ctx* c, const u64* src, u64 stride, bool poly_major, 
     GLP_HIPCHK(c, hipGetLastError());
     u64* prev = digests;
     u64 cnt = nl;
+    // levels of <= coop_max nodes leave most of the chip idle and are latency-bound: there a permutation is spread over 12 lanes
+    // (glp_poseidon_permute_coop), and the last levels (<= 64 nodes) run in one launch.  GLP_COOP_MAX_NODES=0 turns both off.
+    static const u64 coop_max = [] { const char* e = getenv("GLP_COOP_MAX_NODES"); return e ? (u64)atoll(e) : (u64)16384; }();
     for (u32 lvl = log_leaves; lvl > cap_h; lvl--) {
         u64* cur = prev + 4 * cnt;
-        cnt >>= 1;
-        blocks = (cnt + 255) / 256;
-        if (h->small_mds) hipLaunchKernelGGL(glp_merkle_level_kernel<true>, dim3((unsigned)blocks), b, 0, c->stream, prev, cur, cnt, k);
-        else hipLaunchKernelGGL(glp_merkle_level_kernel<false>, dim3((unsigned)blocks), b, 0, c->stream, prev, cur, cnt, k);
+        const u64 out = cnt >> 1;
+        if (coop_max && out <= GLP_COOP_TOP_NODES && out <= coop_max) {          // the rest of the tree in one launch
+            const u32 n_levels = lvl - cap_h;
+            if (h->small_mds) hipLaunchKernelGGL(glp_merkle_top_coop_kernel<true>, dim3(1), dim3(1024), 0, c->stream, prev, cnt, n_levels, k);
+            else hipLaunchKernelGGL(glp_merkle_top_coop_kernel<false>, dim3(1), dim3(1024), 0, c->stream, prev, cnt, n_levels, k);
+            GLP_HIPCHK(c, hipGetLastError());
+            for (u32 l = 0; l < n_levels; l++) { prev += 4 * cnt; cnt >>= 1; }
+            break;
+        }
+        cnt = out;
+        if (coop_max && cnt <= coop_max) {
+            blocks = (cnt * 16 + 255) / 256;
+            if (h->small_mds) hipLaunchKernelGGL(glp_merkle_level_coop_kernel<true>, dim3((unsigned)blocks), b, 0, c->stream, prev, cur, cnt, k);
+            else hipLaunchKernelGGL(glp_merkle_level_coop_kernel<false>, dim3((unsigned)blocks), b, 0, c->stream, prev, cur, cnt, k);
+        } else {
+            blocks = (cnt + 255) / 256;
+            if (h->small_mds) hipLaunchKernelGGL(glp_merkle_level_kernel<true>, dim3((unsigned)blocks), b, 0, c->stream, prev, cur, cnt, k);
+            else hipLaunchKernelGGL(glp_merkle_level_kernel<false>, dim3((unsigned)blocks), b, 0, c->stream, prev, cur, cnt, k);
+        }
         GLP_HIPCHK(c, hipGetLastError());
         prev = cur;
     }

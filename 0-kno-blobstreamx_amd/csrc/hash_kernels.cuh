@@ -41,6 +41,16 @@ struct GlpPoseidonConsts {
 
 #define glp_hfor glp_static_for
 
+// a scheduling fence for the device compiler (no instruction is emitted): keeps it from hoisting the scalar loads of LATER
+// dot-product rows above the current row's arithmetic — hoisted all at once they need > 100 SGPRs and spill into VGPR lanes
+// (v_writelane / v_readlane: 20 % of a partial-round group's VALU instructions before this fence; with it none, VGPRs 69 -> 62,
+// 2^20 x 80 proof 86.7 -> 83.3 ms, wires commitment 46.0 -> 43.0 ms in a same-box A/B: profiles/r02_ab_sched_fence.txt)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GLP_EMU)
+#define GLP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GLP_SCHED_FENCE() ((void)0)
+#endif
+
 // x^7.  Inside a permutation values are kept as arbitrary u64 representatives (products and MDS
 // rows skip the ">= p" check); glp_poseidon_permute canonicalises its 12 outputs once.
 GL_HD u64 glp_sbox7(u64 x) {
@@ -127,8 +137,10 @@ GL_HD void glp_partial_group(u64 (&s)[12], const u32* __restrict__ cf, const u64
     lo[13] = (u32)f2; hi[13] = (u32)(f2 >> 32);
     glp_hfor<0, 12>([&](auto r_) {
         constexpr int r = decltype(r_)::value;
+        GLP_SCHED_FENCE();
         s[r] = glp_dot_small<14>(lo, hi, cf + 25 + 14 * r, cs[2 + r]);
     });
+    GLP_SCHED_FENCE();
 }
 
 // 4 full, 22 partial, 4 full rounds; round = add constants, x^7 (all lanes / lane 0), MDS.
@@ -152,10 +164,13 @@ GL_HD void glp_poseidon_permute(u64 (&s)[12], const GlpPoseidonConsts& k) {
         s[0] = glp_sbox7(s[0]);
         glp_mds_layer<SMALL>(s, k.circ, k.diag, k.rc + (rnd + 1) * 12);
     }
-    for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
+    for (int r = 0; r + 1 < GLP_POS_FULL_HALF; r++, rnd++) {
         glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = glp_sbox7(s[i]); });
-        glp_mds_layer<SMALL>(s, k.circ, k.diag, rnd + 1 < GLP_POS_ROUNDS ? k.rc + (rnd + 1) * 12 : nullptr);
+        glp_mds_layer<SMALL>(s, k.circ, k.diag, k.rc + (rnd + 1) * 12);
     }
+    // the last round has no "next constants": peeled so that the null test is a compile-time fact, not 12 branches per round
+    glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = glp_sbox7(s[i]); });
+    glp_mds_layer<SMALL>(s, k.circ, k.diag, nullptr);
     glp_hfor<0, 12>([&](auto i_) { constexpr int i = decltype(i_)::value; s[i] = gl_canon(s[i]); });
 }
 
@@ -210,6 +225,85 @@ __global__ void __launch_bounds__(256) glp_merkle_level_kernel(const u64* __rest
     glp_hfor<8, 12>([&](auto j_) { constexpr int j = decltype(j_)::value; s[j] = 0; });
     glp_poseidon_permute<SMALL>(s, k);
     glp_hfor<0, 4>([&](auto j_) { constexpr int j = decltype(j_)::value; cur[i * 4 + j] = s[j]; });
+}
+
+// ---- lane-cooperative permutation: 16 lanes per permutation, 12 of them holding one state word each --------------------
+// A Merkle level too small to fill the chip is, one permutation per lane, a ~40 us dependency chain run by a handful of
+// waves (and a proof walks ~7 trees x 10 such levels).  Spreading ONE permutation over 12 lanes cuts the chain ~4x — the S-box
+// of a full round runs on 12 lanes at once, each lane computes its own MDS row — at ~4x the instructions per permutation,
+// a good trade only while most of the chip is idle (levels of <= GLP_COOP_MAX_NODES nodes).  State words cross lanes with
+// wave shuffles (__shfl = ds_bpermute_b32 pairs).  Every lane of the wave must call it (idle lanes included): r = lane & 15,
+// r >= 12 idle; lane_base = first lane of this 16-lane group inside its wave.  x = the lane's state word (canonical).
+template <bool SMALL>
+__device__ __forceinline__ u64 glp_poseidon_permute_coop(u64 x, u32 r, u32 lane_base, const GlpPoseidonConsts& k) {
+    const u32 ri = r < 12u ? r : 0u;
+    x = gl_add(x, k.rc[ri]);
+    const u32 dg = (u32)k.diag[ri];
+    for (int rnd = 0; rnd < GLP_POS_ROUNDS; rnd++) {
+        const bool full = rnd < GLP_POS_FULL_HALF || rnd >= GLP_POS_FULL_HALF + GLP_POS_PARTIAL;
+        const u64 sx = glp_sbox7(x);
+        x = (full || r == 0u) ? sx : x;
+        const u64 kn = (rnd + 1 < GLP_POS_ROUNDS) ? k.rc[(rnd + 1) * 12 + ri] : 0ull;
+        if constexpr (SMALL) {
+            u64 al = (u64)(u32)x * dg + (u32)kn, ah = (u64)(u32)(x >> 32) * dg + (kn >> 32);
+            glp_hfor<0, 12>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                u32 j = ri + (u32)i;
+                if (j >= 12u) j -= 12u;
+                const u64 v = (u64)__shfl((unsigned long long)x, (int)(lane_base + j));
+                al += (u64)(u32)v * (u32)k.circ[i];
+                ah += (u64)(u32)(v >> 32) * (u32)k.circ[i];
+            });
+            x = gl_fold_small(al, ah);
+        } else {
+            x = gl_canon(x);
+            u64 acc = gl_mul(x, k.diag[ri]);
+            glp_hfor<0, 12>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                u32 j = ri + (u32)i;
+                if (j >= 12u) j -= 12u;
+                const u64 v = (u64)__shfl((unsigned long long)x, (int)(lane_base + j));
+                acc = gl_add(acc, gl_mul(v, k.circ[i]));
+            });
+            x = gl_add(acc, kn);
+        }
+    }
+    return gl_canon(x);
+}
+
+// one Merkle level, 16 lanes per node (small levels: see above)
+template <bool SMALL>
+__global__ void __launch_bounds__(256) glp_merkle_level_coop_kernel(const u64* __restrict__ prev, u64* __restrict__ cur, u64 count,
+                                                                    GlpPoseidonConsts k) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 node = t >> 4;
+    const u32 r = threadIdx.x & 15u, lane_base = (threadIdx.x & 63u) & ~15u;
+    const bool active = node < count;
+    u64 x = 0;
+    if (active && r < 8u) x = prev[node * 8 + r];
+    x = glp_poseidon_permute_coop<SMALL>(x, r, lane_base, k);
+    if (active && r < 4u) cur[node * 4 + r] = x;
+}
+
+// the top of a tree in ONE launch: starting from a level of count_prev <= 128 nodes at `prev`, n_levels further levels
+// (each stored right after its predecessor, the layout of glp_merkle), one workgroup, levels handed on through LDS
+#define GLP_COOP_TOP_NODES 64u
+template <bool SMALL>
+__global__ void __launch_bounds__(1024) glp_merkle_top_coop_kernel(u64* __restrict__ prev, u64 count_prev, u32 n_levels, GlpPoseidonConsts k) {
+    __shared__ u64 buf[2][GLP_COOP_TOP_NODES * 4];
+    const u32 node = threadIdx.x >> 4, r = threadIdx.x & 15u, lane_base = (threadIdx.x & 63u) & ~15u;
+    u64 cnt = count_prev;
+    for (u32 l = 0; l < n_levels; l++) {
+        u64* cur = prev + 4 * cnt;
+        cnt >>= 1;
+        const bool active = node < cnt;
+        u64 x = 0;
+        if (active && r < 8u) x = l ? buf[(l - 1) & 1][node * 8 + r] : prev[(u64)node * 8 + r];
+        x = glp_poseidon_permute_coop<SMALL>(x, r, lane_base, k);
+        if (active && r < 4u) { cur[(u64)node * 4 + r] = x; buf[l & 1][node * 4 + r] = x; }
+        __syncthreads();
+        prev = cur;
+    }
 }
 
 // ---- FRI arity-2 fold (row a8) -------------------------------------------------------------

@@ -233,10 +233,21 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                     const u64 p = sbase + col;
                     glp_static_for<0, (int)r>([&](auto d_) {
                         constexpr int d = decltype(d_)::value;
-                        u64 v = a.src[p + ((u64)(row0 + ((u32)d << lsg)) << a.log_m)];
-                        if (a.in_row) v = gl_mul(v, a.in_row[(kcos << LOG_R) + row0 + ((u32)d << lsg)]);
-                        x[g * r + d] = v;
+                        x[g * r + d] = a.src[p + ((u64)(row0 + ((u32)d << lsg)) << a.log_m)];
                     });
+                    if (a.in_row) {
+                        // coset LDE: the input scale.  All r table words are loaded before the first product: written per element
+                        // (load, load, wait, multiply) the compiler serialised every pair behind an s_waitcnt vmcnt(0)
+                        u64 sc[r];
+                        glp_static_for<0, (int)r>([&](auto d_) {
+                            constexpr int d = decltype(d_)::value;
+                            sc[d] = a.in_row[(kcos << LOG_R) + row0 + ((u32)d << lsg)];
+                        });
+                        glp_static_for<0, (int)r>([&](auto d_) {
+                            constexpr int d = decltype(d_)::value;
+                            x[g * r + d] = gl_mul(x[g * r + d], sc[d]);
+                        });
+                    }
                 } else {
                     u64 grow = row_first + col;      // global row handled by this column
                     bool active = grow < total_rows;
@@ -257,10 +268,19 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                     const u32 kc = (u32)poly & coset_mask;
                     glp_static_for<0, (int)r>([&](auto d_) {
                         constexpr int d = decltype(d_)::value;
-                        u64 v = active ? a.src[p + ((u32)d << lsg)] : 0ull;
-                        if (a.in_row) v = gl_mul(v, a.in_row[(kc << LOG_R) + row0 + ((u32)d << lsg)]);   // single-pass sizes: m = 1
-                        x[g * r + d] = v;
+                        x[g * r + d] = active ? a.src[p + ((u32)d << lsg)] : 0ull;
                     });
+                    if (a.in_row) {                                                  // single-pass sizes: m = 1
+                        u64 sc[r];
+                        glp_static_for<0, (int)r>([&](auto d_) {
+                            constexpr int d = decltype(d_)::value;
+                            sc[d] = a.in_row[(kc << LOG_R) + row0 + ((u32)d << lsg)];
+                        });
+                        glp_static_for<0, (int)r>([&](auto d_) {
+                            constexpr int d = decltype(d_)::value;
+                            x[g * r + d] = gl_mul(x[g * r + d], sc[d]);
+                        });
+                    }
                 }
             } else {
                 const u32 base = row0 * ldA + col;

@@ -111,7 +111,7 @@ def emu():
     lib.emu_poseidon_permute.argtypes = [u64p, ctypes.c_uint64, u64p, ctypes.c_int]
     lib.emu_poseidon_grouped_available.argtypes = [u64p]
     lib.emu_merkle.argtypes = [u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u64p, u64p,
-                               ctypes.c_int]
+                               ctypes.c_int, ctypes.c_int]
     lib.emu_fri_fold2.argtypes = [u64p, u64p, ctypes.c_uint32, ctypes.c_uint64, u64p]
     lib.emu_sha256_trace.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]

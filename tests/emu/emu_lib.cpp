@@ -155,7 +155,7 @@ extern "C" int emu_poseidon_permute(u64* states, u64 n, const u64* consts384, in
 }
 
 extern "C" int emu_merkle(const u64* src, u64 stride, int poly_major, u32 leaf_len, u32 log_leaves, u32 cap_h, u64* digests,
-                          const u64* consts384, int small) {
+                          const u64* consts384, int small, int coop_max) {
     std::vector<u32> cf; std::vector<u64> cs;
     GlpPoseidonConsts k = emu_consts(consts384, small, cf, cs);
     const u64 nl = 1ull << log_leaves;
@@ -168,12 +168,26 @@ extern "C" int emu_merkle(const u64* src, u64 stride, int poly_major, u32 leaf_l
     else { if (poly_major) leaves(glp_ic<0>{}, glp_ic<1>{}); else leaves(glp_ic<0>{}, glp_ic<0>{}); }
     u64* prev = digests;
     u64 cnt = nl;
+    // coop_max: levels of at most this many nodes use the lane-cooperative kernels (0 = never), as the product's merkle_impl does
     for (u32 lvl = log_leaves; lvl > cap_h; lvl--) {
         u64* cur = prev + 4 * cnt;
-        cnt >>= 1;
-        unsigned g = (unsigned)((cnt + block - 1) / block);
-        if (small) glp_emu_launch(g, block, 0, [&] { glp_merkle_level_kernel<true>(prev, cur, cnt, k); });
-        else glp_emu_launch(g, block, 0, [&] { glp_merkle_level_kernel<false>(prev, cur, cnt, k); });
+        const u64 out = cnt >> 1;
+        if (coop_max && out <= GLP_COOP_TOP_NODES && out <= (u64)coop_max) {
+            const u32 n_levels = lvl - cap_h;
+            if (small) glp_emu_launch(1, 1024, 0, [&] { glp_merkle_top_coop_kernel<true>(prev, cnt, n_levels, k); });
+            else glp_emu_launch(1, 1024, 0, [&] { glp_merkle_top_coop_kernel<false>(prev, cnt, n_levels, k); });
+            break;
+        }
+        cnt = out;
+        if (coop_max && cnt <= (u64)coop_max) {
+            unsigned g = (unsigned)((cnt * 16 + 255) / 256);
+            if (small) glp_emu_launch(g, 256, 0, [&] { glp_merkle_level_coop_kernel<true>(prev, cur, cnt, k); });
+            else glp_emu_launch(g, 256, 0, [&] { glp_merkle_level_coop_kernel<false>(prev, cur, cnt, k); });
+        } else {
+            unsigned g = (unsigned)((cnt + block - 1) / block);
+            if (small) glp_emu_launch(g, block, 0, [&] { glp_merkle_level_kernel<true>(prev, cur, cnt, k); });
+            else glp_emu_launch(g, block, 0, [&] { glp_merkle_level_kernel<false>(prev, cur, cnt, k); });
+        }
         prev = cur;
     }
     return 0;

@@ -57,13 +57,18 @@ def test_emulated_merkle(emu, oracle, kind, leaf_len, log_leaves, cap_h):
     dig_ref, cap_ref = oracle_merkle(oracle, leaves, cap_h)
     small = 1 if kind == "small" else 0
     dig = np.zeros_like(dig_ref)
-    assert emu.emu_merkle(ptr(leaves), leaf_len, 0, leaf_len, log_leaves, cap_h, ptr(dig), ptr(c384), small) == 0
+    assert emu.emu_merkle(ptr(leaves), leaf_len, 0, leaf_len, log_leaves, cap_h, ptr(dig), ptr(c384), small, 0) == 0
     assert np.array_equal(dig, dig_ref)
     assert np.array_equal(dig[-(1 << cap_h):], cap_ref)
+    # the lane-cooperative kernels (small levels: 16 lanes per node, the last levels fused in one launch) build the same tree
+    for coop_max in (4096, 16):
+        dig3 = np.zeros_like(dig_ref)
+        assert emu.emu_merkle(ptr(leaves), leaf_len, 0, leaf_len, log_leaves, cap_h, ptr(dig3), ptr(c384), small, coop_max) == 0
+        assert np.array_equal(dig3, dig_ref), coop_max
     # polynomial-major source gives the same tree
     polys = np.ascontiguousarray(leaves.T)
     dig2 = np.zeros_like(dig_ref)
-    assert emu.emu_merkle(ptr(polys), 1 << log_leaves, 1, leaf_len, log_leaves, cap_h, ptr(dig2), ptr(c384), 2 if small else 0) == 0
+    assert emu.emu_merkle(ptr(polys), 1 << log_leaves, 1, leaf_len, log_leaves, cap_h, ptr(dig2), ptr(c384), 2 if small else 0, 32) == 0
     assert np.array_equal(dig2, dig_ref)
 
 
