@@ -335,6 +335,30 @@ def _coll_device():
     return "cpu" if _rehearsal() else "cuda"
 
 
+PMC_VALU = os.path.join(ROOT, "profiles", "pmc_valu.json")      # written from the committed rocprofv3 --pmc SQ_INSTS_VALU pass
+SIMDS, PEAK_CLOCK_HZ = 1024, 2.4e9                               # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md max clock
+
+
+def valu_roofline(perms, ms, kind):
+    """the ceiling that actually bounds Poseidon hashing: VALU issue.  peak permutations/s = peak wave-instructions/s x 64 lanes /
+    (VALU instructions per permutation, from the committed PMC pass); achieved = permutations of the stage / its time"""
+    try:
+        with open(PMC_VALU) as f:
+            pm = json.load(f)
+        per, cyc = pm[kind], pm["avg_issue_cycles"]
+    except (OSError, KeyError, ValueError):
+        return None
+    if not perms or ms <= 0 or not per:
+        return None
+    peak = SIMDS * PEAK_CLOCK_HZ / cyc * 64.0 / per / 1e9
+    ach = perms / (ms * 1e-3) / 1e9
+    return {"bound": "valu", "achieved": round(ach, 3), "peak": round(peak, 3), "unit": "G permutations/s", "frac": round(ach / peak, 3),
+            "valu_per_permutation": per, "issue_cycles_per_instruction": cyc,
+            "note": "stage time includes ifft + LDE + every tree level; peak = 1024 SIMDs x 2.4 GHz / issue cycles per wave-instruction "
+                    "(4 for the 64-bit/carry/VOP3 integer class, 2 for v_mov: mix from the ISA) x 64 lanes / VALU instructions per "
+                    "permutation (rocprofv3 SQ_INSTS_VALU): profiles/pmc_valu.json"}
+
+
 def prove_stage_detail(stage_ms, log_n, W, rate_bits=3, cap_h=4):
     """per-stage work of one proof of the build-defined circuit and the rate it was done at (SURVEY.md §5:
     one line per stage with ms, bytes moved, GB/s / permutations per second).  Bytes are ALGORITHMIC (each operand
@@ -367,6 +391,9 @@ def prove_stage_detail(stage_ms, log_n, W, rate_bits=3, cap_h=4):
             d["GBps"] = round(d["bytes"] / (ms * 1e-3) / 1e9, 1)
         if "perms" in d and ms > 0:
             d["Gperm_per_s"] = round(d["perms"] / (ms * 1e-3) / 1e9, 3)
+            vr = valu_roofline(d["perms"], ms, "leaf_hash_valu_per_permutation")
+            if vr:
+                d["roofline"] = vr
         out[name] = d
     return out
 
