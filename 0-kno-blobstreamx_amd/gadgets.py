@@ -1,0 +1,185 @@
+"""In-circuit SHA-256 and the data-commitment circuit built on it (SURVEY.md §8a rows a9/a11 seen from the CIRCUIT side, VERDICT r1
+"missing" item 3 / row g1; upstream names recalled, unverified — reference file:line NONE, the mount is empty: curta's SHA-256 chip,
+blobstreamx ``DataCommitmentCircuit``, plonky2x ``evm_read`` / ``evm_write``).
+
+Round 1 computed the SHA-256 / Merkle witnesses on the GPU (``glp_sha256_trace``, ``glp_tm_merkle_root``) but nothing CONSTRAINED them.
+Here a SHA-256 compression is laid out on ``recursion.CircuitBuilder`` by bit decomposition over the arithmetic gate
+``w = c0*x*y + c1*z + c2`` (no lookup tables in this gate set): xor = a + b - 2ab, Ch = e(f - g) + g, Maj = ab + c(a xor b),
+word additions on packed words followed by a range-checked re-decomposition (35 booleans).  About 66k gates per compression, 20 gates per
+row.  upstream proves its SHA rounds in a separate STARK (curta) and verifies that proof in-circuit; constraining them directly is the
+simplest sound substitute this gate set offers, and is what makes the circuit's public inputs MEAN "this root is the Merkle root of these
+(height, dataRoot) tuples".
+
+``data_commitment_circuit``: public inputs = the tuples (big-endian 32-bit words of abi.encode(height, dataRoot)) followed by the 8 words of
+the commitment root; constraints = every leaf hash SHA256(0x00 || tuple) and inner hash SHA256(0x01 || left || right) of the RFC 6962 /
+Tendermint tree (power-of-two ranges).  The root it exposes equals ``blobstream.data_commitment`` (the GPU witness kernel) and hashlib.
+"""
+import struct
+
+from . import P
+from .recursion import CircuitBuilder
+
+K256 = [
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
+IV256 = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+
+
+class Sha256Gadget:
+    """words are (bits, word): bits = 32 boolean variables LSB first, word = the variable holding their value"""
+
+    def __init__(self, builder):
+        self.b = builder
+        self.one, self.two, self.zero = builder.constant(1), builder.constant(2), builder.constant(0)
+        self.c2_32 = builder.constant(1 << 32)
+
+    # ---- bits -------------------------------------------------------------------------------------------------------------------
+    def xor(self, x, y):
+        s = self.b.arith(1, 1, 0, x, self.one, y)                      # x + y
+        return self.b.arith(P - 2, 1, 0, x, y, s)                      # x + y - 2xy
+
+    def xor3(self, x, y, z):
+        return self.xor(self.xor(x, y), z)
+
+    def ch(self, e, f, g):
+        d = self.b.arith(1, P - 1, 0, f, self.one, g)                  # f - g
+        return self.b.arith(1, 1, 0, e, d, g)                          # e(f - g) + g
+
+    def maj(self, a, bb, c):
+        x = self.xor(a, bb)
+        m = self.b.arith(1, 0, 0, a, bb, a)                            # ab
+        return self.b.arith(1, 1, 0, c, x, m)                          # c(a xor b) + ab
+
+    # ---- words ------------------------------------------------------------------------------------------------------------------
+    def pack(self, bits):
+        """value of a little-endian bit list as one variable (Horner from the top bit)"""
+        acc = bits[-1]
+        for bit in reversed(bits[:-1]):
+            acc = self.b.arith(1, 1, 0, acc, self.two, bit)            # 2*acc + bit
+        return acc
+
+    def word_from_bits(self, bits):
+        return (list(bits), self.pack(bits))
+
+    def const_word(self, v):
+        bits = [self.one if (v >> i) & 1 else self.zero for i in range(32)]
+        return (bits, self.b.constant(v))
+
+    def reduce32(self, total, extra_bits):
+        """total = a sum of words < 2^(32 + extra_bits): returns its low 32 bits as a word.  The decomposition is a range check:
+        32 + extra_bits booleans whose packed value equals total."""
+        v = self.b.value(total)
+        assert v < (1 << (32 + extra_bits))
+        bits = [self.b.var((v >> i) & 1) for i in range(32 + extra_bits)]
+        for bit in bits:
+            self.b.assert_bool(bit)
+        low = self.pack(bits[:32])
+        hi = self.pack(bits[32:])
+        self.b.assert_equal(self.b.arith(1, 1, 0, hi, self.c2_32, low), total)     # hi * 2^32 + low == total
+        return (bits[:32], low)
+
+    def add_words(self, words, const=0):
+        """(sum of the words + const) mod 2^32"""
+        total = words[0][1]
+        for k, w in enumerate(words[1:]):
+            total = self.b.arith(1, 1, const if k == 0 else 0, total, self.one, w[1])
+        if len(words) == 1 and const:
+            total = self.b.arith(1, 0, const, total, self.one, total)
+        n_terms = len(words) + (1 if const else 0)
+        return self.reduce32(total, max(1, (n_terms - 1).bit_length()))
+
+    @staticmethod
+    def rotr(bits, r):
+        return [bits[(i + r) % 32] for i in range(32)]
+
+    def shr(self, bits, r):
+        return [bits[i + r] if i + r < 32 else self.zero for i in range(32)]
+
+    def xor3_words(self, x, y, z):
+        return self.word_from_bits([self.xor3(a, bb, c) for a, bb, c in zip(x, y, z)])
+
+    # ---- compression ------------------------------------------------------------------------------------------------------------
+    def compress(self, state, block_words):
+        """state: 8 words, block_words: 16 words -> 8 words (FIPS 180-4 section 6.2.2)"""
+        w = list(block_words)
+        for t in range(16, 64):
+            s0 = self.xor3_words(self.rotr(w[t - 15][0], 7), self.rotr(w[t - 15][0], 18), self.shr(w[t - 15][0], 3))
+            s1 = self.xor3_words(self.rotr(w[t - 2][0], 17), self.rotr(w[t - 2][0], 19), self.shr(w[t - 2][0], 10))
+            w.append(self.add_words([w[t - 16], s0, w[t - 7], s1]))
+        a, bb, c, d, e, f, g, h = state
+        for t in range(64):
+            S1 = self.xor3_words(self.rotr(e[0], 6), self.rotr(e[0], 11), self.rotr(e[0], 25))
+            chw = self.word_from_bits([self.ch(x, y, z) for x, y, z in zip(e[0], f[0], g[0])])
+            S0 = self.xor3_words(self.rotr(a[0], 2), self.rotr(a[0], 13), self.rotr(a[0], 22))
+            mj = self.word_from_bits([self.maj(x, y, z) for x, y, z in zip(a[0], bb[0], c[0])])
+            # T1 = h + S1 + ch + K[t] + w[t] (kept as an unreduced sum), new e = d + T1, new a = T1 + S0 + maj
+            t1 = self.b.arith(1, 1, K256[t], h[1], self.one, S1[1])
+            t1 = self.b.arith(1, 1, 0, t1, self.one, chw[1])
+            t1 = self.b.arith(1, 1, 0, t1, self.one, w[t][1])                       # < 5 * 2^32
+            new_e = self.reduce32(self.b.arith(1, 1, 0, t1, self.one, d[1]), 3)     # 6 terms
+            t2 = self.b.arith(1, 1, 0, S0[1], self.one, mj[1])
+            new_a = self.reduce32(self.b.arith(1, 1, 0, t1, self.one, t2), 3)       # 7 terms
+            a, bb, c, d, e, f, g, h = new_a, a, bb, c, new_e, e, f, g
+        return [self.add_words([x, y]) for x, y in zip(state, (a, bb, c, d, e, f, g, h))]
+
+    def hash_bits(self, msg_bits):
+        """SHA-256 of a message given as bit variables, MSB first inside each byte (len % 8 == 0): returns 8 words"""
+        n = len(msg_bits)
+        assert n % 8 == 0
+        padded = list(msg_bits) + [self.one] + [self.zero] * ((447 - n) % 512)
+        padded += [self.one if (n >> (63 - i)) & 1 else self.zero for i in range(64)]
+        assert len(padded) % 512 == 0
+        state = [self.const_word(v) for v in IV256]
+        for off in range(0, len(padded), 512):
+            words = []
+            for k in range(16):
+                be = padded[off + 32 * k: off + 32 * k + 32]                         # big-endian: first bit = bit 31
+                words.append(self.word_from_bits(list(reversed(be))))
+            state = self.compress(state, words)
+        return state
+
+    def word_bits_be(self, word):
+        """the 32 bits of a word, most significant first (message order)"""
+        return list(reversed(word[0]))
+
+    def public_word(self, value):
+        """a 32-bit public input: the packed word is the public cell, its bits are range-checked witnesses"""
+        bits = [self.b.var((value >> i) & 1) for i in range(32)]
+        for bit in bits:
+            self.b.assert_bool(bit)
+        w = self.pack(bits)
+        self.b.public_input(w)
+        return (bits, w)
+
+
+def data_commitment_circuit(prover, heights, data_roots):
+    """DataCommitment over a power-of-two block range, constrained in-circuit.  Returns (circuit, device wires, public values,
+    root bytes).  Public values: per block 16 big-endian words of abi.encode(height, dataRoot) (32-byte big-endian height, 32-byte
+    root), then the 8 words of the commitment root."""
+    n = len(heights)
+    assert n >= 1 and n & (n - 1) == 0 and len(data_roots) == n
+    b = CircuitBuilder(prover)
+    g = Sha256Gadget(b)
+    byte_bits = lambda v: [g.one if (v >> (7 - i)) & 1 else g.zero for i in range(8)]
+    level = []
+    for hgt, root in zip(heights, data_roots):
+        tup = int(hgt).to_bytes(32, "big") + bytes(root)
+        words = [g.public_word(struct.unpack(">I", tup[4 * k: 4 * k + 4])[0]) for k in range(16)]
+        msg = byte_bits(0x00) + [bit for w in words for bit in g.word_bits_be(w)]
+        level.append(g.hash_bits(msg))
+    while len(level) > 1:
+        nxt = []
+        for k in range(0, len(level), 2):
+            msg = byte_bits(0x01) + [bit for w in level[k] for bit in g.word_bits_be(w)] + [bit for w in level[k + 1] for bit in g.word_bits_be(w)]
+            nxt.append(g.hash_bits(msg))
+        level = nxt
+    for w in level[0]:
+        b.public_input(w[1])
+    root = b"".join(struct.pack(">I", b.value(w[1])) for w in level[0])
+    ck, dw, public = b.build()
+    return ck, dw, public, root

@@ -130,7 +130,9 @@ class CircuitBuilder:
     # ---- layout ---------------------------------------------------------------------------------------------------------------
     def build(self, cap_height=1):
         """rows: [public inputs][Poseidon rows][arithmetic rows by constants], padded to a power of two.
-        Returns (PlonkCircuit, device wires buffer with the Poseidon rows filled, public values)."""
+        Returns (PlonkCircuit, device wires buffer with the Poseidon rows filled, public values).
+        The cell list is built in Python (one append per placed variable); everything proportional to the table — witness
+        scatter, copy-class cycles, sigma values — is numpy index arithmetic plus the GPU's own field multiplication."""
         W, R, G = self.W, self.R, self.G
         arith = [(key, row) for key, rows in sorted(self.arith_rows.items()) for row in rows if row]
         n_rows = len(self.public) + len(self.pos_rows) + len(arith)
@@ -138,48 +140,58 @@ class CircuitBuilder:
         n = 1 << log_n
         consts = np.zeros((PLONK_NCONST, n), dtype=np.uint64)
         wires = np.zeros((W, n), dtype=np.uint64)
-        cells = {}                                   # class root -> [(wire, row)]
-
-        def place(v, j, i):
-            wires[j, i] = self.values[v]
-            cells.setdefault(self._find(v), []).append((j, i))
+        cj, ci, cv = [], [], []                      # placed cells: wire, row, variable
 
         i = 0
         for v in self.public:
             consts[4, i] = 1
-            place(v, 0, i)
+            cj.append(0); ci.append(i); cv.append(v)
             i += 1
         pos_row_ids = []
         for ins, outs in self.pos_rows:
             consts[5, i] = 1
             for j, v in enumerate(ins):
-                place(v, j, i)
+                cj.append(j); ci.append(i); cv.append(v)
             for j, v in enumerate(outs):
-                place(v, 12 + j, i)
+                cj.append(12 + j); ci.append(i); cv.append(v)
             pos_row_ids.append(i)
             i += 1
         for (c0, c1, c2), row in arith:
             consts[0, i], consts[1, i], consts[2, i], consts[3, i] = 1, c0, c1, c2
-            for g in range(G):
-                if g < len(row):
-                    for k, v in enumerate(row[g]):
-                        place(v, 4 * g + k, i)
-                else:
-                    wires[4 * g + 3, i] = c2                         # an unused slot must still satisfy its gate: w = c2
+            for g, slot in enumerate(row):
+                base = 4 * g
+                cj += (base, base + 1, base + 2, base + 3)
+                ci += (i, i, i, i)
+                cv += slot
+            if len(row) < G and c2:
+                wires[[4 * g + 3 for g in range(len(row), G)], i] = c2      # an unused slot must still satisfy its gate: w = c2
             i += 1
-        # sigma: identity, then one cycle per copy class
-        ks = [pow(7, j, P) for j in range(R)]
-        w = pow(7, (P - 1) >> log_n, P)
-        wp = [1] * n
-        for r in range(1, n):
-            wp[r] = wp[r - 1] * w % P
-        sigma = np.array([[ks[j] * wp[r] % P for r in range(n)] for j in range(R)], dtype=np.uint64)
-        for members in cells.values():
-            if any(j >= R for j, _ in members):
-                raise ValueError("a variable sits on an unrouted wire")
-            for a, (j, r) in enumerate(members):
-                jj, rr = members[(a + 1) % len(members)]
-                sigma[j, r] = ks[jj] * wp[rr] % P
+        cj, ci, cv = np.array(cj, dtype=np.int64), np.array(ci, dtype=np.int64), np.array(cv, dtype=np.int64)
+        if cj.size and int(cj.max()) >= R:
+            raise ValueError("a variable sits on an unrouted wire")
+        vals = np.array(self.values, dtype=np.uint64)
+        wires[cj, ci] = vals[cv]
+        # copy classes: root of every variable (path-compressed once), then one cycle per class over its cells
+        roots = np.array([self._find(v) for v in range(len(self.parent))], dtype=np.int64)
+        cls = roots[cv]
+        order = np.argsort(cls, kind="stable")
+        sc = cls[order]
+        first = np.ones(order.size, dtype=bool)
+        first[1:] = sc[1:] != sc[:-1]
+        start = np.maximum.accumulate(np.where(first, np.arange(order.size), 0))      # index of the group's first cell
+        last = np.ones(order.size, dtype=bool)
+        last[:-1] = first[1:]
+        nxt = np.arange(order.size) + 1
+        nxt[last] = start[last]                                                        # the last cell of a class points back to its first
+        tgt_col = np.tile(np.arange(R, dtype=np.int64)[:, None], (1, n))
+        tgt_row = np.tile(np.arange(n, dtype=np.int64)[None, :], (R, 1))
+        tgt_col[cj[order], ci[order]] = cj[order[nxt]]
+        tgt_row[cj[order], ci[order]] = ci[order[nxt]]
+        ks = np.array([pow(7, j, P) for j in range(R)], dtype=np.uint64)
+        delta = np.zeros(n, dtype=np.uint64)
+        delta[1] = 1
+        wp = self.prover.fft(delta)                                                    # w_n^r, r < n
+        sigma = self.prover.field_op("mul", ks[tgt_col], wp[tgt_row])
         ck = PlonkCircuit(self.prover, consts, sigma, cap_height=cap_height, n_wires=W, n_public=len(self.public), poseidon=True)
         dw = self.prover.to_device(wires)
         self.prover.poseidon_gate_fill_rows(dw, log_n, W, pos_row_ids)               # the 106 S-box-input wires per row, on the GPU
