@@ -246,3 +246,111 @@ def aggregation_key(prover, n_leaves):
     dw.free()
     ck.free()
     return cap
+
+
+# ---- the hashing half of a recursive verifier: every Merkle opening of a child proof, checked in-circuit ---------------------------
+PLONK_TAG = 0x32304B4C504C4747
+FRI_TAG = 0x32304952464C4747
+
+
+def parse_proof(proof):
+    """the words of a circuit proof by role (the layout written by plonk.hip / fri.hip): statement words, caps,
+    and per query the opened leaves and authentication paths of the four batches and of every fold layer.  No verification."""
+    w = [int(v) for v in np.frombuffer(bytes(proof), dtype="<u8")]
+    if w[0] != PLONK_TAG:
+        raise ValueError("not a circuit proof")
+    log_n, rb, cap_h, n_pub = w[1], w[4], w[5], w[6]
+    log_N = log_n + rb
+    capw = 4 << min(cap_h, log_N)
+    pos = 8 + n_pub
+    stmt_end = pos + 4 * capw                      # header || public inputs || four caps: what glp_plonk_proof_digest hashes
+    caps = [w[pos + b * capw: pos + (b + 1) * capw] for b in range(4)]
+    pos = stmt_end
+    if w[pos] != FRI_TAG:
+        raise ValueError("FRI part not found")
+    f_log_n, f_rb, cap0, a, fb, nq, _pow, _shift, nb, n_pts = w[pos + 1: pos + 11]
+    pos += 11 + n_pts
+    n_polys = [w[pos + 2 * b] for b in range(nb)]
+    masks = [w[pos + 2 * b + 1] for b in range(nb)]
+    pos += 2 * nb + nb * (4 << cap0)
+    total = sum(n_polys[b] for p in range(n_pts) for b in range(nb) if (masks[b] >> p) & 1)
+    pos += 2 * total
+    L = (f_log_n - fb) // a if f_log_n > fb else 0
+    final_bits = f_log_n - a * L
+    layer_caps, layer_log, layer_caph = [], [], []
+    log_len = log_N
+    for _ in range(L):
+        chh = min(cap0, log_len - a)
+        layer_caps.append(w[pos: pos + (4 << chh)])
+        pos += 4 << chh
+        layer_log.append(log_len)
+        layer_caph.append(chh)
+        log_len -= a
+    pos += (2 << final_bits) + 1
+    queries = []
+    for _ in range(nq):
+        idx = w[pos]
+        pos += 1
+        trees = []
+        for b in range(nb):
+            leaf = w[pos: pos + n_polys[b]]
+            pos += n_polys[b]
+            plen = log_N - cap0
+            path = [w[pos + 4 * k: pos + 4 * k + 4] for k in range(plen)]
+            pos += 4 * plen
+            trees.append({"leaf": leaf, "path": path, "index": idx, "cap": ("batch", b), "cap_log": cap0})
+        for l in range(L):
+            leaf = w[pos: pos + (2 << a)]
+            pos += 2 << a
+            plen = (layer_log[l] - a) - layer_caph[l]
+            path = [w[pos + 4 * k: pos + 4 * k + 4] for k in range(plen)]
+            pos += 4 * plen
+            trees.append({"leaf": leaf, "path": path, "index": idx >> (a * (l + 1)), "cap": ("layer", l), "cap_log": layer_caph[l]})
+        queries.append(trees)
+    if pos != len(w):
+        raise ValueError("proof length does not match its header")
+    return {"statement": [v % P for v in w[:stmt_end]], "caps": caps, "layer_caps": layer_caps, "queries": queries, "cap_log": cap0}
+
+
+def opening_check_circuit(prover, proofs):
+    """The hashing half of verifying `proofs` (circuit proofs of this library) IN-CIRCUIT.  Public inputs: the 4-word digest of each
+    proof (statement + commitments, = glp_plonk_proof_digest).  Constraints, per proof: the digest is the sponge hash of the statement
+    words and the four caps (so the caps below are the committed ones); for every FRI query and every tree (4 batches + fold layers) the
+    opened leaf hashes, through its authentication path with the index bits choosing left/right, to the cap entry the remaining index bits
+    select.  What is NOT constrained here (still the native verifier's job): that the query indices come from the transcript, and the
+    arithmetic on the opened values (combination, fold consistency, final polynomial, PLONK identity).
+    Returns (circuit, device wires, public values, stats)."""
+    b = CircuitBuilder(prover)
+    n_pos0 = 0
+    stats = {"proofs": len(proofs), "trees": 0}
+    for proof in proofs:
+        pp = parse_proof(proof)
+        stmt = [b.var(v) for v in pp["statement"]]
+        digest = b.hash_no_pad(stmt)
+        for v in digest:
+            b.public_input(v)
+        capw = len(pp["caps"][0])
+        n_stmt = len(stmt)
+        cap_vars = {("batch", k): stmt[n_stmt - (4 - k) * capw: n_stmt - (3 - k) * capw] for k in range(4)}     # bound by the digest
+        for l, lc in enumerate(pp["layer_caps"]):
+            cap_vars[("layer", l)] = [b.var(v) for v in lc]          # fold-layer caps: transcript data, witnesses here
+        for trees in pp["queries"]:
+            for t in trees:
+                plen, clog = len(t["path"]), t["cap_log"]
+                bits = [b.var((t["index"] >> k) & 1) for k in range(plen + clog)]
+                top = b.merkle_root_from_path(b.hash_no_pad([b.var(v) for v in t["leaf"]]), bits[:plen],
+                                              [[b.var(x) for x in s] for s in t["path"]])
+                # the cap entry selected by the remaining index bits: a mux tree over the 2^clog entries
+                entries = [cap_vars[t["cap"]][4 * e: 4 * e + 4] for e in range(1 << clog)]
+                for k in range(clog):
+                    bit = bits[plen + k]
+                    b.assert_bool(bit)
+                    entries = [[b.select(bit, hi, lo) for lo, hi in zip(entries[2 * e], entries[2 * e + 1])] for e in range(len(entries) // 2)]
+                for x, y in zip(top, entries[0]):
+                    b.assert_equal(x, y)
+                stats["trees"] += 1
+    stats["poseidon_rows"] = len(b.pos_rows) - n_pos0
+    stats["arith_gates"] = sum(len(r) for rows in b.arith_rows.values() for r in rows)
+    ck, dw, public = b.build()
+    stats["rows"] = 1 << ck.log_n
+    return ck, dw, public, stats

@@ -475,8 +475,21 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
                    "poseidon_rows": len(digests) - 1, "public_inputs": len(public)}
             dwr.free()
             ckr.free()
+            # the hashing half of a recursive verifier for the first two leaves: every Merkle opening of every FRI query re-hashed in-circuit
+            t5 = time.perf_counter()
+            cko, dwo, pub_o, st = rec.opening_check_circuit(provers[0], proofs[:2])
+            t6 = time.perf_counter()
+            op_proof = cko.prove_(dwo, 28, 16, public=pub_o)
+            t7 = time.perf_counter()
+            agg["opening_check_of_2_leaf_proofs"] = dict(st, build_circuit_seconds=round(t6 - t5, 3), prove_seconds=round(t7 - t6, 4),
+                                                          verified=bool(cko.verify(op_proof, 28, 16, public=pub_o)), proof_bytes=len(op_proof),
+                                                          note="in-circuit: digest = sponge(statement, caps); every opened leaf hashes up its path to "
+                                                               "the cap entry its index bits select.  NOT in-circuit: transcript, fold arithmetic, "
+                                                               "PLONK identity")
+            dwo.free()
+            cko.free()
         except Exception as e:  # noqa: BLE001
-            agg = {"error": f"{type(e).__name__}: {e}"[:200]}
+            agg = dict(agg or {}, error=f"{type(e).__name__}: {e}"[:200])
     if world > 1:
         tt = torch.tensor([dt, dt_red], dtype=torch.float64, device=_coll_device())
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

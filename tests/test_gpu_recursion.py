@@ -148,3 +148,34 @@ def test_sixteen_leaf_proofs_to_one_root_proof(setup, pkg):
     assert res2["ok"] is False and "root_proof" not in res2
     dws[0].free()
     ck.free()
+
+
+def test_in_circuit_merkle_openings_of_two_child_proofs(setup, pkg):
+    """the hashing half of a recursive verifier: for two real child proofs, every Merkle opening of every FRI query (4 batches + the fold
+    layers) is re-hashed in-circuit up to the committed caps, which the in-circuit sponge ties to each proof's public digest.  The circuit's
+    public inputs equal glp_plonk_proof_digest of the children; it proves and verifies; an opening that does not hash to the cap cannot be
+    built into a satisfied circuit"""
+    prover, oracle, rec, mr = setup
+    consts, sigmas, wires = bench.synthetic_circuit(prover, 10, 16)
+    ck = pkg.PlonkCircuit(prover, consts, sigmas)
+    dw = prover.to_device(wires)
+    children = [ck.prove_(dw, 6, 4), ck.prove_(dw, 7, 4)]
+    assert all(ck.verify(p, 6, 4) for p in children)
+    pp = rec.parse_proof(children[0])
+    assert len(pp["queries"]) == 6 and len(pp["queries"][0]) == 4 + len(pp["layer_caps"])
+    rck, rdw, public, stats = rec.opening_check_circuit(prover, children)
+    assert public == prover.proof_digest(children[0]) + prover.proof_digest(children[1])
+    assert stats["trees"] == (6 + 7) * (4 + len(pp["layer_caps"])) and stats["poseidon_rows"] > 500
+    proof = rck.prove_(rdw, 8, 4, public=public)
+    assert rck.verify(proof, 8, 4, public=public), prover.last_reject
+    pref.verify_plonk(proof, oracle, pos_consts=poseidon_consts("small"), public=public)
+    assert not rck.verify(proof, 8, 4, public=public[:5] + [public[5] ^ 1] + public[6:])          # other children: another statement
+    rdw.free()
+    rck.free()
+    # a child whose opened leaf was altered: its path no longer reaches the cap, the builder refuses (assert_equal on different values)
+    w = np.frombuffer(children[0], dtype="<u8").copy()
+    w[-40] ^= np.uint64(1)                                                                        # inside the last query's data
+    with pytest.raises(ValueError):
+        rec.opening_check_circuit(prover, [w.tobytes()])
+    dw.free()
+    ck.free()
