@@ -188,3 +188,24 @@ def verify_aggregate(prover, root_proof, key, digests, root, min_queries=28, min
     circuit ``key`` (recursion.aggregation_key).  The leaf proofs behind the digests are checked by whoever holds them."""
     public = [int(v) for d in digests for v in d] + [int(v) for v in root]
     return prover.plonk_verify(root_proof, key, min_queries, min_pow_bits, public=public)
+
+
+def reduce_recursive(prover, proofs, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4,
+                     root_queries=28, root_pow_bits=16):
+    """The Reduce step as a RECURSION (verifier_circuit.py): rank 0 proves, on the GPU, one circuit that verifies every gathered leaf proof
+    in-circuit (transcript, proof of work, every Merkle opening, FRI combination / folds / final polynomial, PLONK identity) and hashes the
+    leaf digests into a root.  Returns {"root_proof", "public" (leaf public inputs + digests + root), "key" (the recursion circuit's verifying
+    key), "stats"}; whoever checks `root_proof` against (`key`, `public`) needs none of the leaf proofs.  A leaf proof that does not verify
+    makes the circuit impossible to lay down (ValueError)."""
+    import importlib
+    vc = importlib.import_module(__package__ + ".verifier_circuit")
+    size = 1 << max(0, (len(proofs) - 1).bit_length())
+    if size != len(proofs):
+        raise ValueError("reduce_recursive takes a power-of-two number of leaf proofs")
+    ck, dw, public, stats = vc.recursive_aggregation_circuit(prover, proofs, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height)
+    try:
+        root_proof = ck.prove_(dw, root_queries, root_pow_bits, public=public)
+        return {"root_proof": root_proof, "public": public, "key": ck.cap(), "stats": stats}
+    finally:
+        dw.free()
+        ck.free()

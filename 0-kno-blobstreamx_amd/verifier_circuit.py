@@ -1,0 +1,467 @@
+"""The in-circuit verifier of this library's circuit proofs: the recursion step of the MapReduce Reduce (SURVEY.md §8a row a11, §8f item 2;
+upstream names recalled, unverified — reference file:line NONE, the mount is empty: plonky2 ``recursion::recursive_verifier::
+verify_proof``, ``fri::recursive_verifier``, ``iop::challenger::RecursiveChallenger``).
+
+``verify_in_circuit(builder, proof, leaf_key, ...)`` lays down, on ``recursion.CircuitBuilder``, EVERYTHING the native verifier
+(csrc/verify.hip) checks for a proof of an arithmetic-gate circuit (flags = 0: the MapReduce leaf circuit):
+  * the Fiat-Shamir transcript — a duplex sponge of Poseidon rows absorbing the statement, the caps, the openings, the fold-layer caps, the
+    final polynomial and the nonce, squeezing beta, gamma, alpha, zeta, the FRI alpha, the fold betas, the proof-of-work seed and the query
+    indices — so every challenge below is a circuit variable derived from the proof's own words;
+  * the proof of work (one Poseidon row, canonical bit decomposition, top bits zero);
+  * per query: index = low bits of a transcript challenge (canonical decomposition); every Merkle opening (leaf sponge, path with the index
+    bits choosing sides, cap entry chosen by the remaining bits); the batch combination sum alpha^k (f_k(x) - y_k)/(x - z_p) in the
+    quadratic extension; every fold layer (the layer value continues the fold, arity-2^a folding with beta, beta^2, ...); the final polynomial;
+  * the PLONK identity at zeta (L_1, public inputs, permutation argument chunks, arithmetic gates) against the quotient chunks.
+Bound as constants of the verifier circuit: the shape (header words, FRI parameters) and the leaf circuit's verifying key.  Returned: the
+variables of the child's public inputs and of its 4-word digest, for the caller to expose or constrain.
+
+A proof that the native verifier rejects cannot be laid down: some ``assert_equal`` meets two different values and the builder raises.
+"""
+from . import P
+from .recursion import FRI_TAG, PLONK_TAG
+
+W_EXT = 7
+NCONST, CHUNK, NCHAL = 6, 8, 2
+
+
+def _inv(x):
+    return pow(x % P, P - 2, P)
+
+
+def _root(k):
+    return pow(7, (P - 1) >> k, P)
+
+
+def _rev(i, bits):
+    return int(format(i, f"0{bits}b")[::-1], 2) if bits else 0
+
+
+class _G:
+    """base- and extension-field helpers over a CircuitBuilder (extension elements are pairs of variables)"""
+
+    def __init__(self, b):
+        self.b = b
+        self.one, self.zero = b.constant(1), b.constant(0)
+
+    def k(self, v):
+        return self.b.constant(v)
+
+    def lin(self, c1, z, c2=0):
+        """c1 * z + c2"""
+        return self.b.arith(0, c1, c2, z, z, z)
+
+    def mul(self, x, y):
+        return self.b.arith(1, 0, 0, x, y, x)
+
+    def add(self, x, y):
+        return self.b.arith(1, 1, 0, x, self.one, y)
+
+    def sub(self, x, y):
+        return self.b.arith(1, P - 1, 0, x, self.one, y)
+
+    def inv(self, x):
+        """1/x: a witness, checked by one multiplication"""
+        v = self.b.var(_inv(self.b.value(x)))
+        self.b.assert_equal(self.mul(x, v), self.one)
+        return v
+
+    def bit_select_const(self, bit, if1, if0=1):
+        """bit ? if1 : if0 for constants"""
+        return self.lin((if1 - if0) % P, bit, if0)
+
+    def select(self, bit, t, f):
+        return self.b.arith(1, 1, 0, bit, self.sub(t, f), f)
+
+    def bits_canonical(self, x):
+        """the 64 bits (LSB first) of the CANONICAL representative of x: booleans whose packed value is x, and not both
+        (high 32 bits all ones) and (low 32 bits non-zero) — the one pattern of a 64-bit word >= p"""
+        v = self.b.value(x)
+        bits = [self.b.var((v >> i) & 1) for i in range(64)]
+        for bit in bits:
+            self.b.assert_bool(bit)
+        two = self.k(2)
+        lo = bits[31]
+        for bit in reversed(bits[:31]):
+            lo = self.b.arith(1, 1, 0, lo, two, bit)
+        hi = bits[63]
+        for bit in reversed(bits[32:63]):
+            hi = self.b.arith(1, 1, 0, hi, two, bit)
+        self.b.assert_equal(self.b.arith(1, 1, 0, hi, self.k(1 << 32), lo), x)
+        hi_all = bits[32]
+        for bit in bits[33:]:
+            hi_all = self.mul(hi_all, bit)
+        lo_zero = self.lin(P - 1, bits[0], 1)                        # prod (1 - b_i) over the low half
+        for bit in bits[1:32]:
+            lo_zero = self.mul(lo_zero, self.lin(P - 1, bit, 1))
+        lo_nz = self.lin(P - 1, lo_zero, 1)
+        self.b.assert_equal(self.mul(hi_all, lo_nz), self.zero)
+        return bits
+
+    # ---- quadratic extension F_p[X]/(X^2 - 7) --------------------------------------------------------------------------------
+    def e_const(self, v):
+        return (self.k(v[0]), self.k(v[1]))
+
+    def e_val(self, x):
+        return (self.b.value(x[0]), self.b.value(x[1]))
+
+    def e_add(self, x, y):
+        return (self.add(x[0], y[0]), self.add(x[1], y[1]))
+
+    def e_sub(self, x, y):
+        return (self.sub(x[0], y[0]), self.sub(x[1], y[1]))
+
+    def e_mul(self, x, y):
+        t = self.mul(x[1], y[1])
+        c0 = self.b.arith(1, W_EXT, 0, x[0], y[0], t)
+        u = self.mul(x[1], y[0])
+        return (c0, self.b.arith(1, 1, 0, x[0], y[1], u))
+
+    def e_scale(self, x, s):
+        return (self.mul(x[0], s), self.mul(x[1], s))
+
+    def e_scale_const(self, x, c):
+        return (self.lin(c, x[0]), self.lin(c, x[1]))
+
+    def e_muladd_base(self, acc, e, v):
+        """acc + e * v, v in the base field"""
+        return (self.b.arith(1, 1, 0, e[0], v, acc[0]), self.b.arith(1, 1, 0, e[1], v, acc[1]))
+
+    def e_inv(self, x):
+        a, bb = self.e_val(x)
+        n = _inv(a * a - W_EXT * bb * bb)
+        w = (self.b.var(a * n % P), self.b.var((-bb) * n % P))
+        prod = self.e_mul(x, w)
+        self.b.assert_equal(prod[0], self.one)
+        self.b.assert_equal(prod[1], self.zero)
+        return w
+
+    def e_eq(self, x, y):
+        self.b.assert_equal(x[0], y[0])
+        self.b.assert_equal(x[1], y[1])
+
+    def e_select(self, bit, t, f):
+        return (self.select(bit, t[0], f[0]), self.select(bit, t[1], f[1]))
+
+    def e_from_base(self, v):
+        return (v, self.zero)
+
+
+class _Challenger:
+    """the library's duplex sponge (challenger.h), every permutation a constrained Poseidon row"""
+
+    def __init__(self, g):
+        self.g = g
+        self.state = [g.zero] * 12
+        self.inp, self.out = [], []
+
+    def _duplex(self):
+        self.state = self.g.b.poseidon(self.inp + self.state[len(self.inp):])
+        self.inp = []
+        self.out = list(self.state[:8])
+
+    def observe(self, v):
+        self.out = []
+        self.inp.append(v)
+        if len(self.inp) == 8:
+            self._duplex()
+
+    def challenge(self):
+        if self.inp or not self.out:
+            self._duplex()
+        return self.out.pop()
+
+    def ext_challenge(self):
+        a = self.challenge()
+        return (a, self.challenge())
+
+
+def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4):
+    """lay the whole verification of `proof` down on builder `b` (see the module docstring).  The expected statement shape and the leaf
+    circuit's key are CONSTANTS of the resulting circuit.  Returns {"public": [vars], "digest": [4 vars]}."""
+    import numpy as np
+    g = _G(b)
+    words = [int(v) for v in np.frombuffer(bytes(proof), dtype="<u8")]
+    pos = 0
+    R = n_wires if n_routed is None else n_routed
+    M = R // CHUNK
+
+    def take(n):
+        nonlocal pos
+        if pos + n > len(words):
+            raise ValueError("proof truncated")
+        out = words[pos:pos + n]
+        pos += n
+        return out
+
+    def take_vars(n):
+        vs = take(n)
+        if any(v >= P for v in vs):
+            raise ValueError("non-canonical proof word")
+        return [b.var(v) for v in vs]
+
+    ch = _Challenger(g)
+    # ---- statement: header (constants), public inputs, the circuit's key (constants), then the prover's caps ----------------------
+    hdr = take(8)
+    log_n = hdr[1]
+    rb = 3
+    if hdr != [PLONK_TAG, log_n, n_wires, R, rb, cap_height, n_public, 0] or not 3 <= log_n <= 24:
+        raise ValueError("the proof's header is not the expected statement shape")
+    n, log_N = 1 << log_n, log_n + rb
+    N = 1 << log_N
+    cap0 = min(cap_height, log_N)
+    capw = 4 << cap0
+    stmt = [g.k(v % P) for v in hdr]
+    pub = take_vars(n_public)
+    stmt += pub
+    key = [int(v) for v in leaf_key]
+    if take(capw) != key:
+        raise ValueError("the proof is about another circuit (preprocessed cap differs from the key)")
+    cap_pre = [g.k(v) for v in key]
+    for v in stmt + cap_pre:
+        ch.observe(v)
+    cap_wires = take_vars(capw)
+    for v in cap_wires:
+        ch.observe(v)
+    beta = [ch.challenge() for _ in range(NCHAL)]
+    gamma = [ch.challenge() for _ in range(NCHAL)]
+    cap_zs = take_vars(capw)
+    for v in cap_zs:
+        ch.observe(v)
+    alpha = [ch.challenge() for _ in range(NCHAL)]
+    cap_q = take_vars(capw)
+    for v in cap_q:
+        ch.observe(v)
+    digest = b.hash_no_pad(stmt + cap_pre + cap_wires + cap_zs + cap_q)          # = glp_plonk_proof_digest of the child
+    caps = [cap_pre, cap_wires, cap_zs, cap_q]
+
+    # ---- FRI part: parameters are constants of this circuit ---------------------------------------------------------------------
+    a_bits, fb = 4, min(5, log_n)
+    gen = _root(log_n)
+    n_polys = [NCONST + R, n_wires, NCHAL * M, NCHAL << rb]
+    masks = [1, 1, 3, 1]
+    fhdr = [FRI_TAG, log_n, rb, cap0, a_bits, fb, num_queries, pow_bits, 7, 4, 2, 1, gen]
+    for npk, mk in zip(n_polys, masks):
+        fhdr += [npk, mk]
+    if take(len(fhdr)) != fhdr:
+        raise ValueError("the proof's FRI parameters are not the expected ones")
+    for v in fhdr:
+        ch.observe(g.k(v % P))
+    for bi in range(4):
+        if take(capw) != [b.value(v) for v in caps[bi]]:
+            raise ValueError("FRI caps differ from the committed caps")
+        for v in caps[bi]:
+            ch.observe(v)
+    zeta = ch.ext_challenge()
+    order = [(p, bi) for p in range(2) for bi in range(4) if (masks[bi] >> p) & 1]
+    total = sum(n_polys[bi] for _, bi in order)
+    op = take_vars(2 * total)
+    for v in op:
+        ch.observe(v)
+    openings = [(op[2 * k], op[2 * k + 1]) for k in range(total)]
+    alpha_f = ch.ext_challenge()
+    apow = [g.e_from_base(g.one)]
+    for _ in range(total - 1):
+        apow.append(g.e_mul(apow[-1], alpha_f))
+    z_pts = [zeta, g.e_scale_const(zeta, gen)]
+    Ys = [g.e_from_base(g.zero), g.e_from_base(g.zero)]
+    kk = 0
+    for p, bi in order:
+        for _ in range(n_polys[bi]):
+            Ys[p] = g.e_add(Ys[p], g.e_mul(apow[kk], openings[kk]))
+            kk += 1
+    L = (log_n - fb) // a_bits if log_n > fb else 0
+    final_bits = log_n - a_bits * L
+    layer_caps, betas, layer_log, layer_caph = [], [], [], []
+    log_len = log_N
+    for _ in range(L):
+        chh = min(cap0, log_len - a_bits)
+        c = take_vars(4 << chh)
+        for v in c:
+            ch.observe(v)
+        layer_caps.append(c)
+        betas.append(ch.ext_challenge())
+        layer_log.append(log_len)
+        layer_caph.append(chh)
+        log_len -= a_bits
+    fin = take_vars(2 << final_bits)
+    for v in fin:
+        ch.observe(v)
+    final_poly = [(fin[2 * j], fin[2 * j + 1]) for j in range(1 << final_bits)]
+    seed = [ch.challenge() for _ in range(4)]
+    nonce = take_vars(1)[0]
+    if pow_bits:
+        out0 = b.poseidon(seed + [nonce] + [g.zero] * 7)[0]
+        for bit in g.bits_canonical(out0)[64 - pow_bits:]:
+            b.assert_equal(bit, g.zero)
+    ch.observe(nonce)
+    idx_bits = [g.bits_canonical(ch.challenge())[:log_N] for _ in range(num_queries)]
+
+    def merkle_to_cap(leaf_vars, bits, path_vars, cap_vars, cap_log):
+        plen = len(path_vars)
+        top = b.merkle_root_from_path(b.hash_no_pad(leaf_vars), bits[:plen], path_vars)
+        entries = [cap_vars[4 * e: 4 * e + 4] for e in range(1 << cap_log)]
+        for k in range(cap_log):
+            bit = bits[plen + k]
+            entries = [[g.select(bit, hi, lo) for lo, hi in zip(entries[2 * e], entries[2 * e + 1])] for e in range(len(entries) // 2)]
+        for x, y in zip(top, entries[0]):
+            b.assert_equal(x, y)
+
+    def point_from_bits(bits, nbits, shift):
+        """shift * w_{2^nbits}^{rev(index)} for an index given by its bits (LSB first): bit k selects the factor w^(2^(nbits-1-k))"""
+        x = g.k(shift)
+        w = _root(nbits)
+        for k in range(nbits):
+            x = g.mul(x, g.bit_select_const(bits[k], pow(w, 1 << (nbits - 1 - k), P)))
+        return x
+
+    inv2 = _inv(2)
+    for q in range(num_queries):
+        bits = idx_bits[q]
+        idx_val = sum(b.value(bit) << k for k, bit in enumerate(bits))
+        if take(1) != [idx_val]:
+            raise ValueError("query index does not match the transcript")
+        x = point_from_bits(bits, log_N, 7)
+        leaves = []
+        for bi in range(4):
+            leaf = take_vars(n_polys[bi])
+            path = [take_vars(4) for _ in range(log_N - cap0)]
+            merkle_to_cap(leaf, bits, path, caps[bi], cap0)
+            leaves.append(leaf)
+        accs = [g.e_from_base(g.zero), g.e_from_base(g.zero)]
+        k = 0
+        for p, bi in order:
+            for v in leaves[bi]:
+                accs[p] = g.e_muladd_base(accs[p], apow[k], v)
+                k += 1
+        cur = g.e_from_base(g.zero)
+        for p in range(2):
+            den = g.e_sub(g.e_from_base(x), z_pts[p])
+            cur = g.e_add(cur, g.e_mul(g.e_sub(accs[p], Ys[p]), g.e_inv(den)))
+        sh = 7
+        for l in range(L):
+            ll = layer_log[l]
+            leaf = take_vars(2 << a_bits)
+            vals = [(leaf[2 * j], leaf[2 * j + 1]) for j in range(1 << a_bits)]
+            log_leaves = ll - a_bits
+            path = [take_vars(4) for _ in range(log_leaves - layer_caph[l])]
+            lbits = bits[a_bits * l:]                                            # bits of p_l = idx >> (a*l)
+            # the layer value at position p_l & (2^a - 1) continues the fold
+            sel = vals
+            for kbit in range(a_bits):
+                sel = [g.e_select(lbits[kbit], sel[2 * e + 1], sel[2 * e]) for e in range(len(sel) // 2)]
+            g.e_eq(sel[0], cur)
+            merkle_to_cap(leaf, lbits[a_bits:], path, layer_caps[l], layer_caph[l])
+            # T = sh * w_ll^{rev_{ll-a}(leaf_idx)}: the variable part of every coset point; U = 1/T
+            leaf_bits = lbits[a_bits:a_bits + log_leaves]
+            T = g.k(sh)
+            wl = _root(ll)
+            for kbit in range(log_leaves):
+                T = g.mul(T, g.bit_select_const(leaf_bits[kbit], pow(wl, 1 << (log_leaves - 1 - kbit), P)))
+            U = g.inv(T)
+            bt = betas[l]
+            cl = ll
+            for s in range(a_bits):
+                wls = _root(cl)
+                nxt = []
+                for i in range(len(vals) // 2):
+                    cconst = pow(wls, _rev(2 * i, a_bits - s) << log_leaves, P)      # x_i = T_s * cconst
+                    m = g.lin(inv2 * _inv(cconst) % P, U)                            # 1 / (2 x_i)
+                    f0, f1 = vals[2 * i], vals[2 * i + 1]
+                    sm = g.e_scale_const(g.e_add(f0, f1), inv2)
+                    d = g.e_scale(g.e_sub(f0, f1), m)
+                    nxt.append(g.e_add(sm, g.e_mul(bt, d)))
+                vals = nxt
+                cl -= 1
+                bt = g.e_mul(bt, bt)
+                U = g.mul(U, U)
+                sh = sh * sh % P
+            cur = vals[0]
+        fl = log_N - a_bits * L
+        xf = point_from_bits(bits[a_bits * L:], fl, sh)
+        ev = g.e_from_base(g.zero)
+        for cf in reversed(final_poly):
+            ev = g.e_add(g.e_scale(ev, xf), cf)
+        g.e_eq(ev, cur)
+    if pos != len(words):
+        raise ValueError("trailing data in proof")
+
+    # ---- the PLONK identity at zeta ------------------------------------------------------------------------------------------------
+    offs, o = {}, 0
+    for p, bi in order:
+        offs[(p, bi)] = o
+        o += n_polys[bi]
+    pre = openings[offs[(0, 0)]: offs[(0, 0)] + n_polys[0]]
+    wires = openings[offs[(0, 1)]: offs[(0, 1)] + n_polys[1]]
+    zs = openings[offs[(0, 2)]: offs[(0, 2)] + n_polys[2]]
+    quot = openings[offs[(0, 3)]: offs[(0, 3)] + n_polys[3]]
+    zs_next = openings[offs[(1, 2)]: offs[(1, 2)] + n_polys[2]]
+    consts, sigmas = pre[:NCONST], pre[NCONST:]
+    ks = [pow(7, j, P) for j in range(R)]
+    one_e = g.e_from_base(g.one)
+    zn = zeta
+    for _ in range(log_n):
+        zn = g.e_mul(zn, zn)
+    zh = g.e_sub(zn, one_e)
+    # PI(zeta) = sum_i pi_i * w^i (zeta^n - 1) / (n (zeta - w^i))
+    pi_z = g.e_from_base(g.zero)
+    zh_over_n = g.e_scale_const(zh, _inv(n))
+    wi = 1
+    for pv in pub:
+        li = g.e_mul(g.e_scale_const(zh_over_n, wi), g.e_inv(g.e_sub(zeta, g.e_const((wi, 0)))))
+        pi_z = g.e_add(pi_z, g.e_scale(li, pv))
+        wi = wi * gen % P
+    l1 = g.e_mul(zh, g.e_inv(g.e_scale_const(g.e_sub(zeta, one_e), n % P)))
+    q_ar, c0, c1, c2, q_pi, _q_pos = consts
+    for t in range(NCHAL):
+        acc = g.e_mul(l1, g.e_sub(zs[t * M], one_e))
+        ap = alpha[t]
+        acc = g.e_add(acc, g.e_scale(g.e_sub(g.e_mul(q_pi, wires[0]), pi_z), ap))
+        prev = zs[t * M]
+        bx = g.e_scale(zeta, beta[t])
+        for c in range(M):
+            num, den = one_e, one_e
+            for j in range(c * CHUNK, (c + 1) * CHUNK):
+                wg = (g.add(wires[j][0], gamma[t]), wires[j][1])
+                num = g.e_mul(num, g.e_add(wg, g.e_scale_const(bx, ks[j])))
+                den = g.e_mul(den, g.e_add(wg, g.e_scale(sigmas[j], beta[t])))
+            nxt = zs[t * M + 1 + c] if c + 1 < M else zs_next[t * M]
+            perm = g.e_sub(g.e_mul(prev, num), g.e_mul(nxt, den))
+            w8 = wires[c * CHUNK:(c + 1) * CHUNK]
+
+            def gate(xx, yy, zz, ww):
+                return g.e_mul(q_ar, g.e_sub(g.e_add(g.e_add(g.e_mul(c0, g.e_mul(xx, yy)), g.e_mul(c1, zz)), c2), ww))
+            for con in (perm, gate(*w8[0:4]), gate(*w8[4:8])):
+                ap = g.mul(ap, alpha[t])
+                acc = g.e_add(acc, g.e_scale(con, ap))
+            prev = nxt
+        tz, zp = g.e_from_base(g.zero), one_e
+        for c in range(1 << rb):
+            tz = g.e_add(tz, g.e_mul(zp, quot[t * (1 << rb) + c]))
+            zp = g.e_mul(zp, zn)
+        g.e_eq(acc, g.e_mul(zh, tz))
+    return {"public": pub, "digest": digest}
+
+
+def recursive_aggregation_circuit(prover, proofs, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4):
+    """ONE circuit that verifies every proof in `proofs` (all of the same leaf circuit `leaf_key`, same parameters) and folds their digests into a
+    Poseidon Merkle root: the Reduce step as a real recursion, fan-in len(proofs).  Public inputs: each leaf's public inputs, each leaf's
+    4-word digest (leaf order), then the 4-word root.  A verifier of the resulting proof needs no leaf proof: the leaf circuit's key and the
+    leaf parameters are constants of this circuit (part of ITS verifying key)."""
+    from .recursion import CircuitBuilder
+    n = len(proofs)
+    assert n >= 1 and n & (n - 1) == 0, "a power-of-two number of leaves"
+    b = CircuitBuilder(prover)
+    level = []
+    for proof in proofs:
+        out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height)
+        for v in out["public"] + out["digest"]:
+            b.public_input(v)
+        level.append(out["digest"])
+    while len(level) > 1:
+        level = [b.two_to_one(level[2 * k], level[2 * k + 1]) for k in range(len(level) // 2)]
+    for v in level[0]:
+        b.public_input(v)
+    stats = {"leaves": n, "poseidon_rows": len(b.pos_rows), "arith_gates": sum(len(r) for rows in b.arith_rows.values() for r in rows)}
+    ck, dw, public = b.build()
+    stats["rows"] = 1 << ck.log_n
+    return ck, dw, public, stats

@@ -179,3 +179,88 @@ def test_in_circuit_merkle_openings_of_two_child_proofs(setup, pkg):
         rec.opening_check_circuit(prover, [w.tobytes()])
     dw.free()
     ck.free()
+
+
+def _oracle_prover(oracle):
+    class OracleProver:
+        """Poseidon through the CPU oracle: the verifier circuit's logic needs no GPU to be laid down"""
+        def poseidon_permute(self, states):
+            s = np.ascontiguousarray(states, dtype=np.uint64).copy()
+            for i in range(s.shape[0]):
+                row = s[i].copy()
+                oracle.orc_poseidon_permute(ptr(row))
+                s[i] = row
+            return s
+    return OracleProver()
+
+
+@pytest.mark.parametrize("log_n,W,nq,pw", [(7, 8, 5, 3), (10, 16, 6, 4), (13, 8, 4, 5)])
+def test_recursive_verifier_circuit_accepts_real_proofs(setup, pkg, log_n, W, nq, pw):
+    """the FULL verifier in-circuit (transcript, PoW, Merkle openings, combination, 0 / 1 / 2 fold layers, final polynomial, PLONK
+    identity): a real leaf proof can be laid down, the circuit proves and verifies with both verifiers, its public inputs are the leaf's
+    digest; any flipped word of the leaf proof makes the circuit impossible to lay down"""
+    prover, oracle, rec, mr = setup
+    vc = importlib.import_module(graft.PKG_NAME + ".verifier_circuit")
+    rng = np.random.default_rng(log_n)
+    circ = pref.build_circuit(rng, log_n, W)
+    ck = pkg.PlonkCircuit(prover, circ["consts"], circ["sigmas"])
+    leaf = ck.prove(circ["wires"], nq, pw)
+    assert ck.verify(leaf, nq, pw)
+    b = rec.CircuitBuilder(prover)
+    out = vc.verify_in_circuit(b, leaf, ck.cap(), nq, pw, W)
+    for v in out["digest"]:
+        b.public_input(v)
+    rck, rdw, public = b.build()
+    assert public == prover.proof_digest(leaf)
+    proof = rck.prove_(rdw, 8, 4, public=public)
+    assert rck.verify(proof, 8, 4, public=public), prover.last_reject
+    pref.verify_plonk(proof, oracle, pos_consts=poseidon_consts("small"), public=public)
+    rdw.free()
+    rck.free()
+    # tampering: laid down through the CPU oracle (no GPU needed for the logic), every flipped word is refused
+    w = np.frombuffer(leaf, dtype="<u8").copy()
+    op = _oracle_prover(oracle)
+    for t in sorted(set([9, 70, 150, 260, len(w) // 2, len(w) - 30, len(w) - 2] + list(range(300, len(w), max(1, len(w) // 12))))):
+        bad = w.copy()
+        bad[t] ^= np.uint64(1)
+        with pytest.raises(ValueError):
+            vc.verify_in_circuit(rec.CircuitBuilder(op), bad.tobytes(), ck.cap(), nq, pw, W)
+    # ... and a proof of ANOTHER circuit, or weaker parameters than the circuit was built for
+    with pytest.raises(ValueError):
+        vc.verify_in_circuit(rec.CircuitBuilder(op), leaf, ck.cap()[::-1].copy(), nq, pw, W)
+    with pytest.raises(ValueError):
+        vc.verify_in_circuit(rec.CircuitBuilder(op), leaf, ck.cap(), nq + 1, pw, W)
+    ck.free()
+
+
+def test_reduce_as_recursion_four_leaves(setup, pkg):
+    """MapReduce with a recursive Reduce: 4 leaf proofs -> ONE root proof whose circuit verified all four; the root proof's key depends on the
+    leaf circuit and the parameters only, its public inputs are the leaf digests and their root; no leaf proof is needed to check it"""
+    prover, oracle, rec, mr = setup
+    vc = importlib.import_module(graft.PKG_NAME + ".verifier_circuit")
+    consts, sigmas, wires = bench.synthetic_circuit(prover, 10, 16)
+    ck = pkg.PlonkCircuit(prover, consts, sigmas)
+    dw = prover.to_device(wires)
+    nq, pw = 6, 4
+    proofs = mr.map_prove_gather(lambda i: ck.prove_(dw, nq, pw), 4, padded_len=1 << 16)
+    res = mr.reduce_recursive(prover, proofs, ck.cap(), nq, pw, 16, root_queries=10, root_pow_bits=6)
+    digests = [prover.proof_digest(p) for p in proofs]
+    assert res["public"] == [v for d in digests for v in d] + rec.merkle_root_host(prover, digests)
+    assert prover.plonk_verify(res["root_proof"], res["key"], 10, 6, public=res["public"]), prover.last_reject
+    pref.verify_plonk(res["root_proof"], oracle, pos_consts=poseidon_consts("small"), public=res["public"])
+    lie = list(res["public"])
+    lie[2] ^= 1
+    assert not prover.plonk_verify(res["root_proof"], res["key"], 10, 6, public=lie)
+    # the key is a function of the leaf circuit and the parameters, not of the leaf proofs
+    other = mr.map_prove_gather(lambda i: ck.prove_(dw, nq, pw), 4, padded_len=1 << 16)
+    res2 = mr.reduce_recursive(prover, other, ck.cap(), nq, pw, 16, root_queries=10, root_pow_bits=6)
+    assert np.array_equal(res["key"], res2["key"])
+    # one bad leaf: no recursion proof can be made
+    bad = list(proofs)
+    ww = np.frombuffer(bad[2], dtype="<u8").copy()
+    ww[len(ww) // 2] ^= np.uint64(1)
+    bad[2] = ww.tobytes()
+    with pytest.raises(ValueError):
+        mr.reduce_recursive(prover, bad, ck.cap(), nq, pw, 16)
+    dw.free()
+    ck.free()
