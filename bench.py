@@ -488,6 +488,27 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
                                                                "PLONK identity")
             dwo.free()
             cko.free()
+            # ... and the Reduce as a real RECURSION: one circuit that verifies leaf proofs completely in-circuit (verifier_circuit.py) and
+            # hashes their digests into a root.  Fan-in GLP_BENCH_RECURSION_LEAVES (default 4: circuit construction is host Python, ~1 s per leaf)
+            fan = int(os.environ.get("GLP_BENCH_RECURSION_LEAVES", "4"))
+            fan = max(1, min(1 << (fan.bit_length() - 1), len(proofs)))
+            t8 = time.perf_counter()
+            vcm = importlib.import_module(graft.PKG_NAME + ".verifier_circuit")
+            ckv, dwv, pub_v, stv = vcm.recursive_aggregation_circuit(provers[0], proofs[:fan], cks[0].cap(), 28, 16, W)
+            t9 = time.perf_counter()
+            rproof = ckv.prove_(dwv, 28, 16, public=pub_v)
+            t10 = time.perf_counter()
+            rproof = ckv.prove_(dwv, 28, 16, public=pub_v)
+            t11 = time.perf_counter()
+            rok = bool(ckv.verify(rproof, 28, 16, public=pub_v))
+            t12 = time.perf_counter()
+            agg["recursive_reduce"] = dict(stv, wires=ckv.n_wires, build_circuit_seconds=round(t9 - t8, 3), prove_seconds_first=round(t10 - t9, 4),
+                                           prove_seconds=round(t11 - t10, 4), verify_seconds=round(t12 - t11, 4), verified=rok, proof_bytes=len(rproof),
+                                           public_inputs=len(pub_v),
+                                           note="ONE proof whose circuit verified these leaf proofs entirely in-circuit (transcript, PoW, Merkle openings, "
+                                                "FRI, PLONK identity) and hashed their digests to a root; its verifier needs no leaf proof")
+            dwv.free()
+            ckv.free()
         except Exception as e:  # noqa: BLE001
             agg = dict(agg or {}, error=f"{type(e).__name__}: {e}"[:200])
     if world > 1:
@@ -501,8 +522,9 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
            "note": "BASELINE configs[2]/[3] shape with the build-defined leaf circuit (NOT upstream's); seconds = Map + one "
                    "all-gather of padded proofs; Reduce = native verification of every leaf (host arithmetic, split across "
                    "ranks and host threads) + all-reduce of the verdicts, then ONE root proof on rank 0 of the Poseidon Merkle tree over the "
-                   "leaf-proof digests (public inputs: digests + root; every two-to-one hash a constrained Poseidon row).  Still host-checked, "
-                   "not in-circuit: the verification of each leaf proof (no in-circuit FRI verifier yet)"}
+                   "leaf-proof digests (public inputs: digests + root; every two-to-one hash a constrained Poseidon row); "
+                   "aggregation.recursive_reduce = the same Reduce as a real recursion: one circuit that verifies leaf proofs entirely "
+                   "in-circuit (fan-in GLP_BENCH_RECURSION_LEAVES, default 4)"}
     for d, c, q in zip(dws, cks, provers):
         d.free()
         c.free()
