@@ -209,3 +209,48 @@ def reduce_recursive(prover, proofs, leaf_key, num_queries, pow_bits, n_wires, n
     finally:
         dw.free()
         ck.free()
+
+
+def reduce_tree(prover, proofs, leaf, poseidon_consts, fan_in=2, node_queries=28, node_pow_bits=16):
+    """The Reduce step as a TREE of recursions (upstream's shape: plonky2x mapreduce folds leaf proofs pairwise).  Level 1 nodes verify
+    `fan_in` leaf proofs each in-circuit; every later level verifies `fan_in` proofs OF THE PREVIOUS LEVEL — recursion proofs, i.e. Poseidon-row
+    circuits, whose 118 row constraints are then part of the in-circuit identity — until one proof is left.
+    leaf = {"key", "num_queries", "pow_bits", "n_wires", ["n_routed", "n_public", "cap_height"]}: the leaf circuit and its parameters.
+    Returns {"root_proof", "public", "key", "levels": [per level: nodes, rows, prove seconds, build seconds]}.  Every node of one level shares
+    one circuit (and key); a verifier of the root needs the root proof, its public inputs and the last level's key only."""
+    import importlib
+    import time
+    vc = importlib.import_module(__package__ + ".verifier_circuit")
+    params = dict(leaf_key=leaf["key"], num_queries=leaf["num_queries"], pow_bits=leaf["pow_bits"], n_wires=leaf["n_wires"],
+                  n_routed=leaf.get("n_routed"), n_public=leaf.get("n_public", 0), cap_height=leaf.get("cap_height", 4), poseidon_consts=None)
+    cur, levels = list(proofs), []
+    if len(cur) < fan_in or fan_in < 1 or (fan_in & (fan_in - 1)):
+        raise ValueError("reduce_tree: fan_in must be a power of two and at most the number of proofs")
+    while True:
+        if len(cur) % fan_in:
+            raise ValueError("reduce_tree: the number of proofs at a level is not a multiple of fan_in")
+        nxt, key, pub_len, t_build, t_prove, rows = [], None, None, 0.0, 0.0, 0
+        for k in range(0, len(cur), fan_in):
+            t0 = time.perf_counter()
+            ck, dw, public, stats = vc.recursive_aggregation_circuit(prover, cur[k:k + fan_in], **params)
+            t1 = time.perf_counter()
+            try:
+                proof = ck.prove_(dw, node_queries, node_pow_bits, public=public)
+                t2 = time.perf_counter()
+                k_here = ck.cap()
+                if key is not None and (len(public) != pub_len or not (k_here == key).all()):
+                    raise RuntimeError("nodes of one level built different circuits")
+                key, pub_len, rows = k_here, len(public), stats["rows"]
+                nxt.append((proof, public))
+                t_build += t1 - t0
+                t_prove += t2 - t1
+            finally:
+                dw.free()
+                ck.free()
+        levels.append({"nodes": len(nxt), "verifies": "leaf proofs" if params["poseidon_consts"] is None else "recursion proofs", "rows": rows,
+                       "build_circuit_seconds": round(t_build, 3), "prove_seconds": round(t_prove, 4)})
+        if len(nxt) == 1:
+            return {"root_proof": nxt[0][0], "public": nxt[0][1], "key": key, "levels": levels}
+        cur = [p for p, _ in nxt]
+        params = dict(leaf_key=key, num_queries=node_queries, pow_bits=node_pow_bits, n_wires=136, n_routed=80, n_public=pub_len, cap_height=1,
+                      poseidon_consts=poseidon_consts)

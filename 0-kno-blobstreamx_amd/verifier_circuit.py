@@ -3,7 +3,7 @@ upstream names recalled, unverified — reference file:line NONE, the mount is e
 verify_proof``, ``fri::recursive_verifier``, ``iop::challenger::RecursiveChallenger``).
 
 ``verify_in_circuit(builder, proof, leaf_key, ...)`` lays down, on ``recursion.CircuitBuilder``, EVERYTHING the native verifier
-(csrc/verify.hip) checks for a proof of an arithmetic-gate circuit (flags = 0: the MapReduce leaf circuit):
+(csrc/verify.hip) checks for a proof of this library's circuits (the MapReduce leaf circuit, and recursion proofs themselves):
   * the Fiat-Shamir transcript — a duplex sponge of Poseidon rows absorbing the statement, the caps, the openings, the fold-layer caps, the
     final polynomial and the nonce, squeezing beta, gamma, alpha, zeta, the FRI alpha, the fold betas, the proof-of-work seed and the query
     indices — so every challenge below is a circuit variable derived from the proof's own words;
@@ -11,7 +11,8 @@ verify_proof``, ``fri::recursive_verifier``, ``iop::challenger::RecursiveChallen
   * per query: index = low bits of a transcript challenge (canonical decomposition); every Merkle opening (leaf sponge, path with the index
     bits choosing sides, cap entry chosen by the remaining bits); the batch combination sum alpha^k (f_k(x) - y_k)/(x - z_p) in the
     quadratic extension; every fold layer (the layer value continues the fold, arity-2^a folding with beta, beta^2, ...); the final polynomial;
-  * the PLONK identity at zeta (L_1, public inputs, permutation argument chunks, arithmetic gates) against the quotient chunks.
+  * the PLONK identity at zeta (L_1, public inputs, permutation argument chunks, arithmetic gates, and — for a child that is itself a
+    Poseidon-row circuit, e.g. a recursion proof — the 118 Poseidon-row constraints) against the quotient chunks.
 Bound as constants of the verifier circuit: the shape (header words, FRI parameters) and the leaf circuit's verifying key.  Returned: the
 variables of the child's public inputs and of its 4-word digest, for the caller to expose or constrain.
 
@@ -175,9 +176,60 @@ class _Challenger:
         return (a, self.challenge())
 
 
-def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4):
+def _poseidon_row_constraints(g, wires, consts):
+    """the 118 constraint values of a Poseidon row (csrc/plonk_gates.h) on extension-field wire values: the same walk as the gate, S-boxes
+    as extension products, an MDS term as one arithmetic gate per component (acc + const * x)"""
+    rc, circ, diag = consts
+    kc = [g.k(c) for c in circ]
+    kd = [g.k(d) if d else None for d in diag]
+
+    def sbox(x):
+        x2 = g.e_mul(x, x)
+        x3 = g.e_mul(x2, x)
+        x4 = g.e_mul(x2, x2)
+        return g.e_mul(x3, x4)
+
+    def mds(s, rc_next):
+        out = []
+        for r in range(12):
+            acc = g.e_scale(s[r], kd[r]) if kd[r] is not None else g.e_from_base(g.zero)
+            for i in range(12):
+                x = s[(i + r) % 12]
+                acc = (g.b.arith(1, 1, 0, x[0], kc[i], acc[0]), g.b.arith(1, 1, 0, x[1], kc[i], acc[1]))
+            out.append((g.lin(1, acc[0], rc_next[r]), acc[1]) if rc_next is not None else acc)
+        return out
+
+    s = [(g.lin(1, wires[i][0], rc[i]), wires[i][1]) for i in range(12)]
+    out, rnd, aw = [], 0, 24
+    for r in range(4):
+        if r > 0:
+            out += [g.e_sub(wires[aw + i], s[i]) for i in range(12)]
+            s = list(wires[aw:aw + 12])
+            aw += 12
+        s = mds([sbox(v) for v in s], rc[(rnd + 1) * 12:(rnd + 2) * 12])
+        rnd += 1
+    for r in range(22):
+        p = wires[aw]
+        aw += 1
+        out.append(g.e_sub(p, s[0]))
+        s[0] = sbox(p)
+        s = mds(s, rc[(rnd + 1) * 12:(rnd + 2) * 12])
+        rnd += 1
+    for r in range(4):
+        out += [g.e_sub(wires[aw + i], s[i]) for i in range(12)]
+        s = mds([sbox(v) for v in wires[aw:aw + 12]], rc[(rnd + 1) * 12:(rnd + 2) * 12] if rnd + 1 < 30 else None)
+        aw += 12
+        rnd += 1
+    out += [g.e_sub(wires[12 + i], s[i]) for i in range(12)]
+    assert len(out) == 118 and aw == 130
+    return out
+
+
+def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4, poseidon_consts=None):
     """lay the whole verification of `proof` down on builder `b` (see the module docstring).  The expected statement shape and the leaf
-    circuit's key are CONSTANTS of the resulting circuit.  Returns {"public": [vars], "digest": [4 vars]}."""
+    circuit's key are CONSTANTS of the resulting circuit.  poseidon_consts = (rc, circ, diag): the child is a Poseidon-row circuit (flags = 1,
+    e.g. a proof made by this very function's circuit: recursion on recursion); its 118 row constraints are then part of the identity.
+    Returns {"public": [vars], "digest": [4 vars]}."""
     import numpy as np
     g = _G(b)
     words = [int(v) for v in np.frombuffer(bytes(proof), dtype="<u8")]
@@ -204,7 +256,10 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     hdr = take(8)
     log_n = hdr[1]
     rb = 3
-    if hdr != [PLONK_TAG, log_n, n_wires, R, rb, cap_height, n_public, 0] or not 3 <= log_n <= 24:
+    flags = 1 if poseidon_consts is not None else 0
+    if poseidon_consts is not None:
+        poseidon_consts = tuple([int(v) for v in a] for a in poseidon_consts)
+    if hdr != [PLONK_TAG, log_n, n_wires, R, rb, cap_height, n_public, flags] or not 3 <= log_n <= 24:
         raise ValueError("the proof's header is not the expected statement shape")
     n, log_N = 1 << log_n, log_n + rb
     N = 1 << log_N
@@ -411,7 +466,8 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
         pi_z = g.e_add(pi_z, g.e_scale(li, pv))
         wi = wi * gen % P
     l1 = g.e_mul(zh, g.e_inv(g.e_scale_const(g.e_sub(zeta, one_e), n % P)))
-    q_ar, c0, c1, c2, q_pi, _q_pos = consts
+    q_ar, c0, c1, c2, q_pi, q_pos = consts
+    pos_cons = _poseidon_row_constraints(g, wires, poseidon_consts) if flags else []
     for t in range(NCHAL):
         acc = g.e_mul(l1, g.e_sub(zs[t * M], one_e))
         ap = alpha[t]
@@ -434,6 +490,12 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
                 ap = g.mul(ap, alpha[t])
                 acc = g.e_add(acc, g.e_scale(con, ap))
             prev = nxt
+        if flags:
+            pacc = g.e_from_base(g.zero)
+            for con in pos_cons:
+                ap = g.mul(ap, alpha[t])
+                pacc = g.e_add(pacc, g.e_scale(con, ap))
+            acc = g.e_add(acc, g.e_mul(q_pos, pacc))
         tz, zp = g.e_from_base(g.zero), one_e
         for c in range(1 << rb):
             tz = g.e_add(tz, g.e_mul(zp, quot[t * (1 << rb) + c]))
@@ -442,7 +504,8 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     return {"public": pub, "digest": digest}
 
 
-def recursive_aggregation_circuit(prover, proofs, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4):
+def recursive_aggregation_circuit(prover, proofs, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4,
+                                  poseidon_consts=None):
     """ONE circuit that verifies every proof in `proofs` (all of the same leaf circuit `leaf_key`, same parameters) and folds their digests into a
     Poseidon Merkle root: the Reduce step as a real recursion, fan-in len(proofs).  Public inputs: each leaf's public inputs, each leaf's
     4-word digest (leaf order), then the 4-word root.  A verifier of the resulting proof needs no leaf proof: the leaf circuit's key and the
@@ -453,7 +516,7 @@ def recursive_aggregation_circuit(prover, proofs, leaf_key, num_queries, pow_bit
     b = CircuitBuilder(prover)
     level = []
     for proof in proofs:
-        out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height)
+        out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height, poseidon_consts)
         for v in out["public"] + out["digest"]:
             b.public_input(v)
         level.append(out["digest"])

@@ -509,6 +509,14 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
                                                 "FRI, PLONK identity) and hashed their digests to a root; its verifier needs no leaf proof")
             dwv.free()
             ckv.free()
+            # ... and as a TREE: pairs of leaves verified by level-1 nodes, pairs of level-1 (recursion) proofs verified by the level-2 node
+            t13 = time.perf_counter()
+            tree = mr.reduce_tree(provers[0], proofs[:4], {"key": cks[0].cap(), "num_queries": 28, "pow_bits": 16, "n_wires": W},
+                                  (np.array(rc, dtype=np.uint64), np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64)), fan_in=2)
+            t14 = time.perf_counter()
+            agg["reduce_tree_of_4_leaves"] = {"levels": tree["levels"], "seconds_total": round(t14 - t13, 3), "root_proof_bytes": len(tree["root_proof"]),
+                                              "root_public_inputs": len(tree["public"]),
+                                              "root_verifies": bool(provers[0].plonk_verify(tree["root_proof"], tree["key"], 28, 16, public=tree["public"]))}
         except Exception as e:  # noqa: BLE001
             agg = dict(agg or {}, error=f"{type(e).__name__}: {e}"[:200])
     if world > 1:

@@ -264,3 +264,36 @@ def test_reduce_as_recursion_four_leaves(setup, pkg):
         mr.reduce_recursive(prover, bad, ck.cap(), nq, pw, 16)
     dw.free()
     ck.free()
+
+
+def test_recursion_on_recursion_reduce_tree(setup, pkg):
+    """a Reduce TREE: 4 leaf proofs -> 2 nodes that each verify 2 leaves in-circuit -> 1 root that verifies the 2 node proofs in-circuit
+    (recursion proofs are Poseidon-row circuits: their 118 row constraints are evaluated in-circuit at zeta).  The root is accepted by both
+    verifiers for exactly its public inputs; a bad leaf stops the tree at level 1"""
+    prover, oracle, rec, mr = setup
+    consts = poseidon_consts("small")
+    c, s, wv = bench.synthetic_circuit(prover, 9, 16)
+    ck = pkg.PlonkCircuit(prover, c, s)
+    dw = prover.to_device(wv)
+    nq, pw = 5, 3
+    leaves = [ck.prove_(dw, nq, pw) for _ in range(4)]
+    leaf = {"key": ck.cap(), "num_queries": nq, "pow_bits": pw, "n_wires": 16}
+    res = mr.reduce_tree(prover, leaves, leaf, consts, fan_in=2, node_queries=6, node_pow_bits=4)
+    assert [lv["nodes"] for lv in res["levels"]] == [2, 1] and res["levels"][1]["verifies"] == "recursion proofs"
+    assert prover.plonk_verify(res["root_proof"], res["key"], 6, 4, public=res["public"]), prover.last_reject
+    pref.verify_plonk(res["root_proof"], oracle, pos_consts=consts, public=res["public"])
+    lie = list(res["public"])
+    lie[-1] ^= 1
+    assert not prover.plonk_verify(res["root_proof"], res["key"], 6, 4, public=lie)
+    # the leaf digests are among the root's public inputs (each level exposes its children's public inputs and digests)
+    for p in leaves:
+        d = prover.proof_digest(p)
+        assert any(res["public"][k:k + 4] == d for k in range(len(res["public"]) - 3))
+    bad = list(leaves)
+    ww = np.frombuffer(bad[3], dtype="<u8").copy()
+    ww[200] ^= np.uint64(1)
+    bad[3] = ww.tobytes()
+    with pytest.raises(ValueError):
+        mr.reduce_tree(prover, bad, leaf, consts, fan_in=2, node_queries=6, node_pow_bits=4)
+    dw.free()
+    ck.free()
