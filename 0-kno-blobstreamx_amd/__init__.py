@@ -182,6 +182,8 @@ def load_library():
         "glp_poseidon_gate_fill_rows": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint32]),
         "glp_plonk_proof_digest": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
         "glp_plonk_proof_digest_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+        "glp_witness_eval": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
+                                            ctypes.POINTER(ctypes.c_size_t)]),
         "glp_comm_unique_id": (ctypes.c_int, [_vp]),
         "glp_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
         "glp_comm_rank": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

@@ -584,6 +584,82 @@ extern "C" int glp_plonk_proof_digest_host(const uint64_t* h_rc, const uint64_t*
     return proof_digest(h, proof, len, h_out4);
 }
 
+// ---- witness evaluator for circuits recorded by the host builder (recursion.py::WitnessProgram) -------------------------------------
+// A recorded circuit is a straight-line program over its variables: arithmetic gates, free inputs, bit extractions, inverses, Poseidon
+// permutations — each op defines NEW variables from earlier ones, so one forward pass computes the whole witness.  The dependency chain is
+// sequential (host work by nature, like the transcript); different proofs/circuits evaluate independently.  Program words (u64):
+//   0 ARITH  w x y z c0 c1 c2   w = c0*x*y + c1*z + c2        1 INPUT w i          w = inputs[i]
+//   2 BIT    w x k              w = bit k of canonical x        3 INV   w x          w = 1/x (0 -> 0)
+//   4 EINV   w0 w1 x0 x1        (w0,w1) = 1/(x0 + x1 X)          5 ZERO  w            w = 0
+//   6 POSEIDON o0..o11 i0..i11  outputs = permutation(inputs)
+// eq_pairs: 2*n_eq variable indices that must hold equal values (the circuit's copy constraints between DIFFERENT variables): the first
+// violated pair is reported through *first_bad and the call returns GLP_E_REJECT — the witness does not satisfy the circuit (e.g. the
+// verifier circuit was fed a proof that does not verify).
+extern "C" int glp_witness_eval(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint64_t* prog, size_t prog_words,
+                                const uint64_t* inputs, size_t n_inputs, uint64_t* values, size_t n_values, const uint64_t* eq_pairs, size_t n_eq,
+                                size_t* first_bad) {
+    Hasher h;
+    glp_challenger ch;
+    if (!prog || !values || (!inputs && n_inputs) || (!eq_pairs && n_eq) || !make_hasher_from(h_rc, h_mds_circ, h_mds_diag, h, ch)) return GLP_E_INVALID;
+    size_t pc = 0;
+    auto ok = [&](u64 v) { return v < n_values; };
+    while (pc < prog_words) {
+        const u64 op = prog[pc];
+        const u64* a = prog + pc + 1;
+        switch (op) {
+            case 0: {
+                if (pc + 8 > prog_words || !ok(a[0]) || !ok(a[1]) || !ok(a[2]) || !ok(a[3]) || a[4] >= GL_P || a[5] >= GL_P || a[6] >= GL_P) return GLP_E_INVALID;
+                values[a[0]] = gl_add(gl_add(gl_mul(a[4], gl_mul(values[a[1]], values[a[2]])), gl_mul(a[5], values[a[3]])), a[6]);
+                pc += 8;
+                break;
+            }
+            case 1:
+                if (pc + 3 > prog_words || !ok(a[0]) || a[1] >= n_inputs || inputs[a[1]] >= GL_P) return GLP_E_INVALID;
+                values[a[0]] = inputs[a[1]];
+                pc += 3;
+                break;
+            case 2:
+                if (pc + 4 > prog_words || !ok(a[0]) || !ok(a[1]) || a[2] >= 64) return GLP_E_INVALID;
+                values[a[0]] = (values[a[1]] >> a[2]) & 1ull;
+                pc += 4;
+                break;
+            case 3:
+                if (pc + 3 > prog_words || !ok(a[0]) || !ok(a[1])) return GLP_E_INVALID;
+                values[a[0]] = values[a[1]] ? gl_inv(values[a[1]]) : 0;
+                pc += 3;
+                break;
+            case 4: {
+                if (pc + 5 > prog_words || !ok(a[0]) || !ok(a[1]) || !ok(a[2]) || !ok(a[3])) return GLP_E_INVALID;
+                const gl_ext2 x{values[a[2]], values[a[3]]};
+                const gl_ext2 r = (x.a || x.b) ? ext_inv(x) : gl_ext2{0, 0};
+                values[a[0]] = r.a; values[a[1]] = r.b;
+                pc += 5;
+                break;
+            }
+            case 5:
+                if (pc + 2 > prog_words || !ok(a[0])) return GLP_E_INVALID;
+                values[a[0]] = 0;
+                pc += 2;
+                break;
+            case 6: {
+                if (pc + 25 > prog_words) return GLP_E_INVALID;
+                u64 st[12];
+                for (int i = 0; i < 12; i++) { if (!ok(a[i]) || !ok(a[12 + i])) return GLP_E_INVALID; st[i] = values[a[12 + i]]; }
+                h.permute(st);
+                for (int i = 0; i < 12; i++) values[a[i]] = st[i];
+                pc += 25;
+                break;
+            }
+            default: return GLP_E_INVALID;
+        }
+    }
+    for (size_t k = 0; k < n_eq; k++) {
+        if (!ok(eq_pairs[2 * k]) || !ok(eq_pairs[2 * k + 1])) return GLP_E_INVALID;
+        if (values[eq_pairs[2 * k]] != values[eq_pairs[2 * k + 1]]) { if (first_bad) *first_bad = k; return GLP_E_REJECT; }
+    }
+    return GLP_OK;
+}
+
 extern "C" int glp_plonk_proof_public_inputs(const uint8_t* proof, size_t len, uint64_t* h_out, size_t* n_words) {
     if (!proof_args_ok(proof, len) || !n_words || (!h_out && *n_words)) return GLP_E_INVALID;
     const u64* w = (const u64*)proof;

@@ -75,7 +75,7 @@ class Sha256Gadget:
         32 + extra_bits booleans whose packed value equals total."""
         v = self.b.value(total)
         assert v < (1 << (32 + extra_bits))
-        bits = [self.b.var((v >> i) & 1) for i in range(32 + extra_bits)]
+        bits = [self.b.bit(total, i) for i in range(32 + extra_bits)]
         for bit in bits:
             self.b.assert_bool(bit)
         low = self.pack(bits[:32])
@@ -149,10 +149,11 @@ class Sha256Gadget:
 
     def public_word(self, value):
         """a 32-bit public input: the packed word is the public cell, its bits are range-checked witnesses"""
-        bits = [self.b.var((value >> i) & 1) for i in range(32)]
+        w = self.b.var(value)                               # the program's input; its bits are computed witnesses, range-checked here
+        bits = [self.b.bit(w, i) for i in range(32)]
         for bit in bits:
             self.b.assert_bool(bit)
-        w = self.pack(bits)
+        self.b.assert_equal(self.pack(bits), w)
         self.b.public_input(w)
         return (bits, w)
 

@@ -31,12 +31,43 @@ class CircuitBuilder:
         self.pos_rows = []               # (in vars[12], out vars[12])
         self.public = []
         self._consts = {}
+        # the straight-line program that recomputes every variable from the free inputs (WitnessProgram / glp_witness_eval)
+        self.prog = []                   # flat op words (encoding: csrc/verify.hip)
+        self.input_tags = []             # per free input: caller's tag (e.g. (proof number, word position)) or None
+        self.eq_pairs = []               # copy constraints between different variables
+        self.word_checks = []            # ("const", tag, value) / ("var", tag, variable) / ("bits", tag, [bit variables]): facts about input
+        #                                  words that are checked outside the circuit when a recorded program is replayed
 
     # ---- variables and copy constraints ---------------------------------------------------------------------------------------
-    def var(self, value):
+    def _new(self, value):
         self.values.append(int(value) % P)
         self.parent.append(len(self.parent))
         return len(self.values) - 1
+
+    def var(self, value, tag=None):
+        """a free witness value (an INPUT of the recorded program); tag says where a replay finds it"""
+        v = self._new(value)
+        self.prog += (1, v, len(self.input_tags))
+        self.input_tags.append(tag)
+        return v
+
+    def bit(self, x, k):
+        """bit k of the canonical value of x (a computed witness: the caller still has to constrain it)"""
+        v = self._new((self.values[x] >> k) & 1)
+        self.prog += (2, v, x, k)
+        return v
+
+    def inverse(self, x):
+        v = self._new(pow(self.values[x], P - 2, P))
+        self.prog += (3, v, x)
+        return v
+
+    def ext_inverse(self, x0, x1):
+        a, bb = self.values[x0], self.values[x1]
+        n = pow((a * a - 7 * bb * bb) % P, P - 2, P)
+        w0, w1 = self._new(a * n), self._new((-bb) * n)
+        self.prog += (4, w0, w1, x0, x1)
+        return w0, w1
 
     def _find(self, a):
         while self.parent[a] != a:
@@ -51,6 +82,7 @@ class CircuitBuilder:
         ra, rb = self._find(a), self._find(b)
         if ra != rb:
             self.parent[ra] = rb
+            self.eq_pairs += (a, b)
 
     def value(self, v):
         return self.values[v]
@@ -59,7 +91,8 @@ class CircuitBuilder:
     def arith(self, c0, c1, c2, x, y, z):
         """w = c0*x*y + c1*z + c2 (one slot of a row whose constants are (c0, c1, c2))"""
         key = (int(c0) % P, int(c1) % P, int(c2) % P)
-        w = self.var(key[0] * self.values[x] * self.values[y] + key[1] * self.values[z] + key[2])
+        w = self._new(key[0] * self.values[x] * self.values[y] + key[1] * self.values[z] + key[2])
+        self.prog += (0, w, x, y, z, key[0], key[1], key[2])
         rows = self.arith_rows.setdefault(key, [[]])
         if len(rows[-1]) == self.G:
             rows.append([])
@@ -69,7 +102,8 @@ class CircuitBuilder:
     def constant(self, k):
         k = int(k) % P
         if k not in self._consts:
-            d = self.var(0)
+            d = self._new(0)
+            self.prog += (5, d)
             self._consts[k] = self.arith(0, 0, k, d, d, d)
         return self._consts[k]
 
@@ -96,7 +130,8 @@ class CircuitBuilder:
         """one permutation row; ins: 12 variables -> 12 output variables (values from the GPU's own permutation)"""
         assert len(ins) == 12
         out = self.prover.poseidon_permute(np.array([[self.values[v] for v in ins]], dtype=np.uint64))[0]
-        outs = [self.var(int(v)) for v in out]
+        outs = [self._new(int(v)) for v in out]
+        self.prog += (6, *outs, *ins)
         self.pos_rows.append((list(ins), outs))
         return outs
 
@@ -128,33 +163,47 @@ class CircuitBuilder:
         return cur
 
     # ---- layout ---------------------------------------------------------------------------------------------------------------
+    def program(self):
+        """the recorded circuit as a WitnessProgram: layout (constants, cells, sigma recipe) + the straight-line witness program"""
+        return WitnessProgram(self)
+
     def build(self, cap_height=1):
         """rows: [public inputs][Poseidon rows][arithmetic rows by constants], padded to a power of two.
-        Returns (PlonkCircuit, device wires buffer with the Poseidon rows filled, public values).
-        The cell list is built in Python (one append per placed variable); everything proportional to the table — witness
-        scatter, copy-class cycles, sigma values — is numpy index arithmetic plus the GPU's own field multiplication."""
-        W, R, G = self.W, self.R, self.G
-        arith = [(key, row) for key, rows in sorted(self.arith_rows.items()) for row in rows if row]
-        n_rows = len(self.public) + len(self.pos_rows) + len(arith)
-        log_n = max(3, (max(n_rows, 1) - 1).bit_length())
-        n = 1 << log_n
-        consts = np.zeros((PLONK_NCONST, n), dtype=np.uint64)
-        wires = np.zeros((W, n), dtype=np.uint64)
-        cj, ci, cv = [], [], []                      # placed cells: wire, row, variable
+        Returns (PlonkCircuit, device wires buffer with the Poseidon rows filled, public values) for the values recorded while building."""
+        prog = self.program()
+        ck = prog.setup(self.prover, cap_height)
+        dw, public = prog.device_witness(self.prover, np.array(self.values, dtype=np.uint64))
+        return ck, dw, public
 
+
+class WitnessProgram:
+    """A circuit recorded by CircuitBuilder, separated from the witness it was recorded with: the layout (which variable sits in which cell,
+    the constant columns, sigma) and the program that recomputes every variable from the free inputs.  `setup` commits the circuit once;
+    `evaluate` + `device_witness` make the wire matrix for NEW inputs without touching the Python builder again (glp_witness_eval, host C++)."""
+
+    def __init__(self, b):
+        W, R, G = b.W, b.R, b.G
+        self.W, self.R = W, R
+        arith = [(key, row) for key, rows in sorted(b.arith_rows.items()) for row in rows if row]
+        n_rows = len(b.public) + len(b.pos_rows) + len(arith)
+        self.log_n = max(3, (max(n_rows, 1) - 1).bit_length())
+        n = 1 << self.log_n
+        consts = np.zeros((PLONK_NCONST, n), dtype=np.uint64)
+        fixed = []                                   # (wire, row, value): cells of unused gate slots that must hold c2
+        cj, ci, cv = [], [], []                      # placed cells: wire, row, variable
         i = 0
-        for v in self.public:
+        for v in b.public:
             consts[4, i] = 1
             cj.append(0); ci.append(i); cv.append(v)
             i += 1
-        pos_row_ids = []
-        for ins, outs in self.pos_rows:
+        self.pos_row_ids = []
+        for ins, outs in b.pos_rows:
             consts[5, i] = 1
             for j, v in enumerate(ins):
                 cj.append(j); ci.append(i); cv.append(v)
             for j, v in enumerate(outs):
                 cj.append(12 + j); ci.append(i); cv.append(v)
-            pos_row_ids.append(i)
+            self.pos_row_ids.append(i)
             i += 1
         for (c0, c1, c2), row in arith:
             consts[0, i], consts[1, i], consts[2, i], consts[3, i] = 1, c0, c1, c2
@@ -164,16 +213,27 @@ class CircuitBuilder:
                 ci += (i, i, i, i)
                 cv += slot
             if len(row) < G and c2:
-                wires[[4 * g + 3 for g in range(len(row), G)], i] = c2      # an unused slot must still satisfy its gate: w = c2
+                fixed += [(4 * g + 3, i, c2) for g in range(len(row), G)]      # an unused slot must still satisfy its gate: w = c2
             i += 1
-        cj, ci, cv = np.array(cj, dtype=np.int64), np.array(ci, dtype=np.int64), np.array(cv, dtype=np.int64)
-        if cj.size and int(cj.max()) >= R:
+        self.consts = consts
+        self.cj, self.ci, self.cv = np.array(cj, dtype=np.int64), np.array(ci, dtype=np.int64), np.array(cv, dtype=np.int64)
+        if self.cj.size and int(self.cj.max()) >= R:
             raise ValueError("a variable sits on an unrouted wire")
-        vals = np.array(self.values, dtype=np.uint64)
-        wires[cj, ci] = vals[cv]
-        # copy classes: root of every variable (path-compressed once), then one cycle per class over its cells
-        roots = np.array([self._find(v) for v in range(len(self.parent))], dtype=np.int64)
-        cls = roots[cv]
+        self.fixed = fixed
+        self.public_vars = np.array(b.public, dtype=np.int64)
+        self.roots = np.array([b._find(v) for v in range(len(b.parent))], dtype=np.int64)
+        self.n_values = len(b.values)
+        self.prog = np.array(b.prog, dtype=np.uint64)
+        self.eq_pairs = np.array(b.eq_pairs, dtype=np.uint64)
+        self.input_tags = list(b.input_tags)
+        self.word_checks = list(b.word_checks)
+        self.stats = {"rows": n, "poseidon_rows": len(b.pos_rows), "arith_gates": sum(len(r) for _, r in arith), "variables": self.n_values,
+                      "inputs": len(self.input_tags)}
+
+    def setup(self, prover, cap_height=1):
+        """commit the circuit (constants + sigma): one cycle per copy class over its cells, sigma values by the GPU's field multiplication"""
+        R, n = self.R, 1 << self.log_n
+        cls = self.roots[self.cv]
         order = np.argsort(cls, kind="stable")
         sc = cls[order]
         first = np.ones(order.size, dtype=bool)
@@ -185,17 +245,72 @@ class CircuitBuilder:
         nxt[last] = start[last]                                                        # the last cell of a class points back to its first
         tgt_col = np.tile(np.arange(R, dtype=np.int64)[:, None], (1, n))
         tgt_row = np.tile(np.arange(n, dtype=np.int64)[None, :], (R, 1))
-        tgt_col[cj[order], ci[order]] = cj[order[nxt]]
-        tgt_row[cj[order], ci[order]] = ci[order[nxt]]
+        tgt_col[self.cj[order], self.ci[order]] = self.cj[order[nxt]]
+        tgt_row[self.cj[order], self.ci[order]] = self.ci[order[nxt]]
         ks = np.array([pow(7, j, P) for j in range(R)], dtype=np.uint64)
         delta = np.zeros(n, dtype=np.uint64)
         delta[1] = 1
-        wp = self.prover.fft(delta)                                                    # w_n^r, r < n
-        sigma = self.prover.field_op("mul", ks[tgt_col], wp[tgt_row])
-        ck = PlonkCircuit(self.prover, consts, sigma, cap_height=cap_height, n_wires=W, n_public=len(self.public), poseidon=True)
-        dw = self.prover.to_device(wires)
-        self.prover.poseidon_gate_fill_rows(dw, log_n, W, pos_row_ids)               # the 106 S-box-input wires per row, on the GPU
-        return ck, dw, [self.values[v] for v in self.public]
+        wp = prover.fft(delta)                                                         # w_n^r, r < n
+        sigma = prover.field_op("mul", ks[tgt_col], wp[tgt_row])
+        return PlonkCircuit(prover, self.consts, sigma, cap_height=cap_height, n_wires=self.W, n_public=len(self.public_vars), poseidon=True)
+
+    def evaluate(self, poseidon_consts, inputs):
+        """every variable's value for new inputs (glp_witness_eval); ValueError when the inputs do not satisfy the circuit's copy constraints"""
+        import ctypes
+        from . import load_library
+        lib = load_library()
+        rc, circ, diag = (np.ascontiguousarray(a, dtype=np.uint64) for a in poseidon_consts)
+        inp = np.ascontiguousarray(inputs, dtype=np.uint64)
+        if inp.size != len(self.input_tags):
+            raise ValueError(f"{inp.size} inputs given, the program takes {len(self.input_tags)}")
+        vals = np.zeros(self.n_values, dtype=np.uint64)
+        bad = ctypes.c_size_t(0)
+        rcode = lib.glp_witness_eval(rc.ctypes.data, circ.ctypes.data, diag.ctypes.data, self.prog.ctypes.data, self.prog.size,
+                                     inp.ctypes.data if inp.size else None, inp.size, vals.ctypes.data, vals.size,
+                                     self.eq_pairs.ctypes.data if self.eq_pairs.size else None, self.eq_pairs.size // 2, ctypes.byref(bad))
+        if rcode == -7:
+            raise ValueError(f"the inputs do not satisfy the circuit (copy constraint {bad.value} fails)")
+        if rcode != 0:
+            raise ValueError("witness program or inputs malformed")
+        return vals
+
+    def inputs_from_words(self, word_lists):
+        """the input vector of a program whose inputs were tagged (list number, word position) — e.g. the proofs a verifier circuit consumes —
+        after checking the recorded facts about the non-input words (constants of the statement shape, the circuit's key)"""
+        ws = [np.frombuffer(bytes(w), dtype="<u8") if isinstance(w, (bytes, bytearray)) else np.asarray(w, dtype=np.uint64) for w in word_lists]
+        for kind, tag, val in self.word_checks:
+            k, pos = tag
+            if pos >= ws[k].size or (kind == "const" and int(ws[k][pos]) != val):
+                raise ValueError(f"input {k}: word {pos} is not what this circuit was built for")
+        out = np.zeros(len(self.input_tags), dtype=np.uint64)
+        for i, tag in enumerate(self.input_tags):
+            if tag is None:
+                raise ValueError("this program has untagged inputs: pass the input vector itself")
+            k, pos = tag
+            if pos >= ws[k].size:
+                raise ValueError(f"input {k} is shorter than the program expects")
+            out[i] = ws[k][pos]
+        return out, ws
+
+    def check_words(self, vals, ws):
+        """the recorded facts that tie non-input words to computed variables (redundant copies inside a proof)"""
+        for kind, tag, val in self.word_checks:
+            k, pos = tag
+            if kind == "var" and int(ws[k][pos]) != int(vals[val]):
+                raise ValueError(f"input {k}: word {pos} differs from the value the circuit derives")
+            if kind == "bits" and int(ws[k][pos]) != sum(int(vals[bv]) << j for j, bv in enumerate(val)):
+                raise ValueError(f"input {k}: word {pos} differs from the index the transcript derives")
+
+    def device_witness(self, prover, vals):
+        """variable values -> wire matrix on the device, Poseidon rows' advice wires filled by the GPU; returns (buffer, public values)"""
+        n = 1 << self.log_n
+        wires = np.zeros((self.W, n), dtype=np.uint64)
+        for j, i, v in self.fixed:
+            wires[j, i] = v
+        wires[self.cj, self.ci] = vals[self.cv]
+        dw = prover.to_device(wires)
+        prover.poseidon_gate_fill_rows(dw, self.log_n, self.W, self.pos_row_ids)
+        return dw, [int(v) for v in vals[self.public_vars]]
 
 
 # ---- the Reduce step's aggregation tree -----------------------------------------------------------------------------------------

@@ -62,7 +62,7 @@ class _G:
 
     def inv(self, x):
         """1/x: a witness, checked by one multiplication"""
-        v = self.b.var(_inv(self.b.value(x)))
+        v = self.b.inverse(x)
         self.b.assert_equal(self.mul(x, v), self.one)
         return v
 
@@ -76,8 +76,7 @@ class _G:
     def bits_canonical(self, x):
         """the 64 bits (LSB first) of the CANONICAL representative of x: booleans whose packed value is x, and not both
         (high 32 bits all ones) and (low 32 bits non-zero) — the one pattern of a 64-bit word >= p"""
-        v = self.b.value(x)
-        bits = [self.b.var((v >> i) & 1) for i in range(64)]
+        bits = [self.b.bit(x, i) for i in range(64)]
         for bit in bits:
             self.b.assert_bool(bit)
         two = self.k(2)
@@ -128,9 +127,7 @@ class _G:
         return (self.b.arith(1, 1, 0, e[0], v, acc[0]), self.b.arith(1, 1, 0, e[1], v, acc[1]))
 
     def e_inv(self, x):
-        a, bb = self.e_val(x)
-        n = _inv(a * a - W_EXT * bb * bb)
-        w = (self.b.var(a * n % P), self.b.var((-bb) * n % P))
+        w = self.b.ext_inverse(x[0], x[1])
         prod = self.e_mul(x, w)
         self.b.assert_equal(prod[0], self.one)
         self.b.assert_equal(prod[1], self.zero)
@@ -225,7 +222,8 @@ def _poseidon_row_constraints(g, wires, consts):
     return out
 
 
-def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4, poseidon_consts=None):
+def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4, poseidon_consts=None,
+                      proof_id=0):
     """lay the whole verification of `proof` down on builder `b` (see the module docstring).  The expected statement shape and the leaf
     circuit's key are CONSTANTS of the resulting circuit.  poseidon_consts = (rc, circ, diag): the child is a Poseidon-row circuit (flags = 1,
     e.g. a proof made by this very function's circuit: recursion on recursion); its 118 row constraints are then part of the identity.
@@ -245,22 +243,31 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
         pos += n
         return out
 
+    def take_const(expected, what):
+        """words that must equal constants of this circuit (shape, key): checked now, and recorded for replays of the program"""
+        p0 = pos
+        if take(len(expected)) != list(expected):
+            raise ValueError(what)
+        b.word_checks += [("const", (proof_id, p0 + i), int(v)) for i, v in enumerate(expected)]
+
     def take_vars(n):
+        p0 = pos
         vs = take(n)
         if any(v >= P for v in vs):
             raise ValueError("non-canonical proof word")
-        return [b.var(v) for v in vs]
+        return [b.var(v, tag=(proof_id, p0 + i)) for i, v in enumerate(vs)]
 
     ch = _Challenger(g)
     # ---- statement: header (constants), public inputs, the circuit's key (constants), then the prover's caps ----------------------
-    hdr = take(8)
-    log_n = hdr[1]
+    log_n = words[1] if len(words) > 1 else 0
     rb = 3
     flags = 1 if poseidon_consts is not None else 0
     if poseidon_consts is not None:
         poseidon_consts = tuple([int(v) for v in a] for a in poseidon_consts)
-    if hdr != [PLONK_TAG, log_n, n_wires, R, rb, cap_height, n_public, flags] or not 3 <= log_n <= 24:
+    if not 3 <= log_n <= 24:
         raise ValueError("the proof's header is not the expected statement shape")
+    hdr = [PLONK_TAG, log_n, n_wires, R, rb, cap_height, n_public, flags]
+    take_const(hdr, "the proof's header is not the expected statement shape")
     n, log_N = 1 << log_n, log_n + rb
     N = 1 << log_N
     cap0 = min(cap_height, log_N)
@@ -269,8 +276,7 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     pub = take_vars(n_public)
     stmt += pub
     key = [int(v) for v in leaf_key]
-    if take(capw) != key:
-        raise ValueError("the proof is about another circuit (preprocessed cap differs from the key)")
+    take_const(key, "the proof is about another circuit (preprocessed cap differs from the key)")
     cap_pre = [g.k(v) for v in key]
     for v in stmt + cap_pre:
         ch.observe(v)
@@ -297,13 +303,17 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     fhdr = [FRI_TAG, log_n, rb, cap0, a_bits, fb, num_queries, pow_bits, 7, 4, 2, 1, gen]
     for npk, mk in zip(n_polys, masks):
         fhdr += [npk, mk]
-    if take(len(fhdr)) != fhdr:
-        raise ValueError("the proof's FRI parameters are not the expected ones")
+    take_const(fhdr, "the proof's FRI parameters are not the expected ones")
     for v in fhdr:
         ch.observe(g.k(v % P))
     for bi in range(4):
+        p0 = pos
         if take(capw) != [b.value(v) for v in caps[bi]]:
             raise ValueError("FRI caps differ from the committed caps")
+        if bi:
+            b.word_checks += [("var", (proof_id, p0 + i), v) for i, v in enumerate(caps[bi])]
+        else:
+            b.word_checks += [("const", (proof_id, p0 + i), kv) for i, kv in enumerate(key)]
         for v in caps[bi]:
             ch.observe(v)
     zeta = ch.ext_challenge()
@@ -373,6 +383,7 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     for q in range(num_queries):
         bits = idx_bits[q]
         idx_val = sum(b.value(bit) << k for k, bit in enumerate(bits))
+        b.word_checks.append(("bits", (proof_id, pos), list(bits)))
         if take(1) != [idx_val]:
             raise ValueError("query index does not match the transcript")
         x = point_from_bits(bits, log_N, 7)
@@ -439,6 +450,7 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
         g.e_eq(ev, cur)
     if pos != len(words):
         raise ValueError("trailing data in proof")
+    b.word_checks.append(("const", (proof_id, 1), log_n))           # (also pins the proof length through the shape)
 
     # ---- the PLONK identity at zeta ------------------------------------------------------------------------------------------------
     offs, o = {}, 0
@@ -515,8 +527,8 @@ def recursive_aggregation_circuit(prover, proofs, leaf_key, num_queries, pow_bit
     assert n >= 1 and n & (n - 1) == 0, "a power-of-two number of leaves"
     b = CircuitBuilder(prover)
     level = []
-    for proof in proofs:
-        out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height, poseidon_consts)
+    for k, proof in enumerate(proofs):
+        out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height, poseidon_consts, proof_id=k)
         for v in out["public"] + out["digest"]:
             b.public_input(v)
         level.append(out["digest"])
@@ -528,3 +540,52 @@ def recursive_aggregation_circuit(prover, proofs, leaf_key, num_queries, pow_bit
     ck, dw, public = b.build()
     stats["rows"] = 1 << ck.log_n
     return ck, dw, public, stats
+
+
+class RecursionProgram:
+    """The recursion circuit for N proofs of ONE leaf circuit, recorded once and replayed for every later batch: `__init__` lays the circuit down
+    from a sample batch (Python builder, seconds) and commits it; `prove(proofs)` evaluates the witness program on new proofs (glp_witness_eval,
+    milliseconds of host C++), uploads the wires and proves on the GPU.  A batch containing a proof that does not verify is refused
+    (ValueError): some copy constraint of the verifier circuit fails on its witness."""
+
+    def __init__(self, prover, sample_proofs, leaf_key, num_queries, pow_bits, n_wires, poseidon_values, n_routed=None, n_public=0, cap_height=4,
+                 child_is_recursion=False):
+        from .recursion import CircuitBuilder
+        n = len(sample_proofs)
+        assert n >= 1 and n & (n - 1) == 0, "a power-of-two number of proofs"
+        self.prover, self.consts = prover, poseidon_values
+        b = CircuitBuilder(prover)
+        level = []
+        for k, proof in enumerate(sample_proofs):
+            out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height,
+                                    poseidon_values if child_is_recursion else None, proof_id=k)
+            for v in out["public"] + out["digest"]:
+                b.public_input(v)
+            level.append(out["digest"])
+        while len(level) > 1:
+            level = [b.two_to_one(level[2 * k], level[2 * k + 1]) for k in range(len(level) // 2)]
+        for v in level[0]:
+            b.public_input(v)
+        self.program = b.program()
+        self.circuit = self.program.setup(prover)
+        self.stats = dict(self.program.stats, leaves=n)
+
+    def key(self):
+        return self.circuit.cap()
+
+    def witness(self, proofs):
+        inputs, ws = self.program.inputs_from_words(proofs)
+        vals = self.program.evaluate(self.consts, inputs)
+        self.program.check_words(vals, ws)
+        return self.program.device_witness(self.prover, vals)
+
+    def prove(self, proofs, num_queries=28, pow_bits=16):
+        """(root proof, public inputs) for a batch of proofs of the leaf circuit"""
+        dw, public = self.witness(proofs)
+        try:
+            return self.circuit.prove_(dw, num_queries, pow_bits, public=public), public
+        finally:
+            dw.free()
+
+    def free(self):
+        self.circuit.free()

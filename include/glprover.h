@@ -275,6 +275,13 @@ int glp_plonk_proof_public_inputs(const uint8_t* h_proof, size_t proof_len, uint
 /* 4-word Poseidon digest of a circuit proof's statement and commitments: hash_no_pad(header || public inputs || the four caps) —
  * the leaf value of the Reduce step's aggregation tree (0-kno-blobstreamx_amd/recursion.py).  No verification. */
 int glp_plonk_proof_digest(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_len, uint64_t* h_out4);
+/* Witness evaluator for circuits recorded by the host builder (0-kno-blobstreamx_amd/recursion.py::WitnessProgram): a straight-line program
+ * (arithmetic gates, inputs, bit extractions, inverses, Poseidon permutations; encoding in csrc/verify.hip) computes every variable of the circuit
+ * from its inputs in one forward pass, then the copy constraints between different variables (eq_pairs, 2 indices each) are checked:
+ * GLP_E_REJECT + *first_bad when the witness does not satisfy the circuit.  Host arithmetic: the chain is sequential, like the transcript. */
+int glp_witness_eval(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint64_t* prog, size_t prog_words,
+                     const uint64_t* inputs, size_t n_inputs, uint64_t* values, size_t n_values, const uint64_t* eq_pairs, size_t n_eq,
+                     size_t* first_bad);
 int glp_plonk_proof_digest_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
                                 size_t proof_len, uint64_t* h_out4);
 

@@ -1,0 +1,141 @@
+"""The recorded witness program (recursion.WitnessProgram + glp_witness_eval, host C++): a circuit laid down once by the Python builder is
+re-evaluated for new inputs without the builder.  CPU: the C evaluator reproduces every variable the builder computed for the golden proofs'
+verifier circuits (Poseidon through the library's host permutation vs the oracle's), refuses tampered inputs, and the SHA-256 gadget's program
+hashes NEW messages.  GPU: a recursion circuit recorded from one batch of leaf proofs proves other batches."""
+import hashlib
+import importlib
+import json
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import plonk_ref as pref  # noqa: E402
+from conftest import P, poseidon_consts, ptr  # noqa: E402
+import __graft_entry__ as graft  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _mods():
+    graft.load_package()
+    return tuple(importlib.import_module(graft.PKG_NAME + m) for m in (".recursion", ".verifier_circuit", ".gadgets", ".mapreduce"))
+
+
+def _oracle_prover(oracle):
+    class OracleProver:
+        def poseidon_permute(self, states):
+            s = np.ascontiguousarray(states, dtype=np.uint64).copy()
+            for i in range(s.shape[0]):
+                row = s[i].copy()
+                oracle.orc_poseidon_permute(ptr(row))
+                s[i] = row
+            return s
+    return OracleProver()
+
+
+@pytest.mark.parametrize("which", ["plonk", "gates"])
+def test_c_evaluator_reproduces_the_builders_witness(oracle, which):
+    rec, vc, _, _ = _mods()
+    consts = poseidon_consts("small")
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    with open(os.path.join(G, "proofs.json")) as f:
+        g = json.load(f)[which]
+    proof = bytes.fromhex(g["proof"])
+    b = rec.CircuitBuilder(_oracle_prover(oracle))
+    kw = dict(n_routed=g.get("R"), n_public=g.get("n_public", 0), poseidon_consts=consts if which == "gates" else None)
+    vc.verify_in_circuit(b, proof, g["circuit_cap"], g["queries"], g["pow_bits"], g["W"], **kw)
+    prog = b.program()
+    inputs, ws = prog.inputs_from_words([proof])
+    vals = prog.evaluate(consts, inputs)
+    assert np.array_equal(vals, np.array(b.values, dtype=np.uint64)), "the C evaluator and the Python builder disagree on a variable"
+    prog.check_words(vals, ws)
+    # tampered proofs: a flipped input word breaks a copy constraint, a flipped constant word is caught before evaluation
+    w = np.frombuffer(proof, dtype="<u8").copy()
+    refused = 0
+    targets = list(range(0, len(w), max(1, len(w) // 50)))
+    for t in targets:
+        bad = w.copy()
+        bad[t] ^= np.uint64(1)
+        try:
+            i2, ws2 = prog.inputs_from_words([bad.tobytes()])
+            prog.check_words(prog.evaluate(consts, i2), ws2)
+        except ValueError:
+            refused += 1
+    assert refused == len(targets)
+    assert prog.stats["inputs"] == len(inputs) and prog.stats["variables"] == len(vals)
+
+
+def test_sha256_program_hashes_new_messages(oracle):
+    """the SHA-256 gadget recorded for one 64-byte message, replayed by the C evaluator for others"""
+    rec, _, gd, _ = _mods()
+    consts = poseidon_consts("small")
+    b = rec.CircuitBuilder(object())
+    g = gd.Sha256Gadget(b)
+    first = bytes(range(64))
+    words = [g.public_word(struct.unpack(">I", first[4 * k: 4 * k + 4])[0]) for k in range(16)]
+    state = g.hash_bits([bit for w in words for bit in g.word_bits_be(w)])
+    digest_vars = [w[1] for w in state]
+    assert b"".join(struct.pack(">I", b.value(v)) for v in digest_vars) == hashlib.sha256(first).digest()
+    prog = b.program()
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        msg = rng.integers(0, 256, 64, dtype=np.uint8).tobytes()
+        vals = prog.evaluate(consts, [struct.unpack(">I", msg[4 * k: 4 * k + 4])[0] for k in range(16)])
+        assert b"".join(struct.pack(">I", int(vals[v])) for v in digest_vars) == hashlib.sha256(msg).digest()
+    with pytest.raises(ValueError):
+        prog.evaluate(consts, [1 << 33] + [0] * 15)                 # a "word" that is not 32 bits: the range check fails
+
+
+def _witness_for(circ, rng):
+    """another satisfying witness of a copy-free arithmetic circuit: fresh inputs, outputs by the gate equation"""
+    q, c0, c1, c2 = ([int(v) for v in circ["consts"][k]] for k in range(4))
+    W, n = circ["W"], 1 << circ["log_n"]
+    w = [[int(rng.integers(0, 1 << 62)) * 4 % P for _ in range(n)] for _ in range(W)]
+    for i in range(n):
+        if q[i]:
+            for gidx in range(W // 4):
+                x, y, z = w[4 * gidx][i], w[4 * gidx + 1][i], w[4 * gidx + 2][i]
+                w[4 * gidx + 3][i] = (c0[i] * x * y + c1[i] * z + c2[i]) % P
+    return np.array(w, dtype=np.uint64)
+
+
+@pytest.mark.gpu
+def test_recursion_program_recorded_once_proves_other_batches(prover, oracle, pkg):
+    """the recursion circuit is laid down ONCE (Python builder) from a sample batch of leaf proofs; other batches — proofs of the same leaf
+    circuit for other witnesses — are proved through the recorded program (C evaluator + GPU), with the same key; a bad proof is refused"""
+    rec, vc, _, mr = _mods()
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    rng = np.random.default_rng(77)
+    circ = pref.build_circuit(rng, 9, 16, copy_prob=0.0)
+    ck = pkg.PlonkCircuit(prover, circ["consts"], circ["sigmas"])
+    nq, pw = 6, 4
+    batches = [[ck.prove(_witness_for(circ, rng), nq, pw) for _ in range(2)] for _ in range(3)]
+    assert len({p for bt in batches for p in bt}) == 6 and all(ck.verify(p, nq, pw) for bt in batches for p in bt)
+    rp = vc.RecursionProgram(prover, batches[0], ck.cap(), nq, pw, 16, consts)
+    for bt in batches:
+        proof, public = rp.prove(bt, 8, 4)
+        digests = [prover.proof_digest(p) for p in bt]
+        assert public == [v for d in digests for v in d] + rec.merkle_root_host(prover, digests)
+        assert prover.plonk_verify(proof, rp.key(), 8, 4, public=public), prover.last_reject
+    pref.verify_plonk(proof, oracle, pos_consts=consts, public=public)
+    # the recorded circuit is the circuit a fresh build would make
+    ck2, dw2, pub2, _ = vc.recursive_aggregation_circuit(prover, batches[2], ck.cap(), nq, pw, 16)
+    assert np.array_equal(ck2.cap(), rp.key()) and pub2 == public
+    dw2.free()
+    ck2.free()
+    bad = list(batches[1])
+    ww = np.frombuffer(bad[1], dtype="<u8").copy()
+    ww[len(ww) // 3] ^= np.uint64(1)
+    bad[1] = ww.tobytes()
+    with pytest.raises(ValueError):
+        rp.prove(bad, 8, 4)
+    with pytest.raises(ValueError):
+        rp.prove(batches[1][:1] + [batches[1][1][:-8]], 8, 4)
+    rp.free()
+    ck.free()
