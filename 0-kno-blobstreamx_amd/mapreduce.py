@@ -91,9 +91,9 @@ def map_prove_gather(prove_leaf, n_leaves, padded_len, device=None, comm=None):
     ``leaves_of_rank(n_leaves, rank, world)`` with ``prove_leaf(i) -> bytes`` — or a LIST of such callables,
     one per concurrent prover of this rank, each run by its own host thread — (e.g.
     ``PlonkCircuit.prove`` of the leaf circuit on leaf i's witness), then every rank receives all
-    proofs in leaf order through ONE all-gather.  The Reduce step upstream is a tree of recursive
-    verifier circuits; in this build the gathered proofs are checked by the host-side verifier
-    (no in-circuit recursion yet — DESIGN.md §7), so what is returned is the ordered proof list."""
+    proofs in leaf order through ONE all-gather.  What is returned is the ordered proof list; the Reduce step
+    consumes it: ``reduce_verify`` (native verification), ``reduce_aggregate`` (digest tree proof), ``reduce_recursive`` /
+    ``reduce_tree`` (the leaf proofs verified in-circuit: verifier_circuit.py)."""
     rank, world = _world(comm)
     ids = leaves_of_rank(n_leaves, rank, world)
     mine, failure = None, None

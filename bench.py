@@ -586,8 +586,8 @@ def data_commitment_leg(pkg, n_blocks=4):
 def mapreduce_bench(leaves_per_rank=16, log_n=16, W=80):
     """BASELINE configs[2]/[3] shape (skip / batch leaves): Map = one leaf proof per leaf, leaf i on
     rank i % world; exchange = one all-gather of padded proofs (RCCL when launched under
-    torch.distributed.run, a no-op on one rank).  Leaf circuit = the build-defined circuit; the
-    recursive Reduce step is not built, so the time reported is map + gather."""
+    torch.distributed.run, a no-op on one rank).  Leaf circuit = the build-defined circuit; `seconds` is map + gather, the Reduce
+    forms (native verification, aggregation tree, recursive verification) are reported beside it under `aggregation`."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
