@@ -184,6 +184,9 @@ def load_library():
         "glp_plonk_proof_digest_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
         "glp_witness_eval": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
                                             ctypes.POINTER(ctypes.c_size_t)]),
+        "glp_witness_eval_mt": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
+                                               ctypes.POINTER(ctypes.c_size_t), _vp, ctypes.c_size_t, ctypes.c_uint32]),
+        "glp_gather_u64": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
         "glp_comm_unique_id": (ctypes.c_int, [_vp]),
         "glp_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
         "glp_comm_rank": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
@@ -720,6 +723,10 @@ class Prover:
             self.sync()
         finally:
             dr.free()
+
+    def gather(self, d_dst, d_src, n_src, d_index, n):
+        """d_dst[i] = d_src[d_index[i]] (0xFFFFFFFF -> 0), all on the device: witness placement (glp_gather_u64)"""
+        self._chk(self.lib.glp_gather_u64(self.ctx, _ptr(d_dst), _ptr(d_src), n_src, _ptr(d_index), n), "glp_gather_u64")
 
     def ed25519_witness(self, pubs, sigs, msgs):
         """pubs/sigs/msgs: lists of bytes.  Returns [n][37] u64 records (glprover.h)."""

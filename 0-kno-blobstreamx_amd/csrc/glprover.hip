@@ -622,6 +622,39 @@ extern "C" int glp_field_op(glp_ctx* c, int op, const uint64_t* a, const uint64_
     return GLP_OK;
 }
 
+// witness placement: wire cell i takes the variable its index entry names (0xFFFFFFFF = an unused cell, zero)
+__global__ void __launch_bounds__(256) glp_witness_place_kernel(u64* __restrict__ dst, const u64* __restrict__ src, u64 n_src, const u32* __restrict__ index,
+                                                         u64 n, u32* __restrict__ bad) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u32 k = index[i];
+        u64 v = 0;
+        if (k != 0xFFFFFFFFu) {
+            if (k < n_src) v = src[k];
+            else atomicOr(bad, 1u);
+        }
+        dst[i] = v;
+    }
+}
+
+extern "C" int glp_gather_u64(glp_ctx* c, uint64_t* d_dst, const uint64_t* d_src, size_t n_src, const uint32_t* d_index, size_t n) {
+    if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
+    if ((!d_dst || !d_index || (!d_src && n_src)) && n) { glp_set_err(c, "glp_gather_u64: bad argument"); return GLP_E_INVALID; }
+    if (n == 0) return GLP_OK;
+    GlpPoolBuf flag(c);
+    if (flag.alloc(256) != hipSuccess) return GLP_E_HIP;
+    GLP_HIPCHK(c, hipMemsetAsync(flag.p, 0, 4, c->stream));
+    u64 blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(glp_witness_place_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_dst, d_src, (u64)n_src, d_index, (u64)n, (u32*)flag.p);
+    GLP_HIPCHK(c, hipGetLastError());
+    u32 bad = 0;
+    GLP_HIPCHK(c, hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bad) { glp_set_err(c, "glp_gather_u64: an index entry is out of range"); return GLP_E_INVALID; }
+    return GLP_OK;
+}
+
 extern "C" int glp_transpose(glp_ctx* c, const uint64_t* in, uint64_t* out, uint64_t rows, uint64_t cols) {
     if (!c) return GLP_E_INVALID;
     GLP_BIND(c);

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "glp_ctx.h"
 #include "hash_state.h"
@@ -595,41 +597,53 @@ extern "C" int glp_plonk_proof_digest_host(const uint64_t* h_rc, const uint64_t*
 // eq_pairs: 2*n_eq variable indices that must hold equal values (the circuit's copy constraints between DIFFERENT variables): the first
 // violated pair is reported through *first_bad and the call returns GLP_E_REJECT — the witness does not satisfy the circuit (e.g. the
 // verifier circuit was fed a proof that does not verify).
-extern "C" int glp_witness_eval(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint64_t* prog, size_t prog_words,
-                                const uint64_t* inputs, size_t n_inputs, uint64_t* values, size_t n_values, const uint64_t* eq_pairs, size_t n_eq,
-                                size_t* first_bad) {
-    Hasher h;
-    glp_challenger ch;
-    if (!prog || !values || (!inputs && n_inputs) || (!eq_pairs && n_eq) || !make_hasher_from(h_rc, h_mds_circ, h_mds_diag, h, ch)) return GLP_E_INVALID;
-    size_t pc = 0;
+// One range [pc, end) of a witness program.  OWNED: the range is a parallel segment with id `me` — it may read only variables written by the
+// prefix (owner 0) or by itself, and write only variables nobody has written, so concurrent segments cannot race; the owner table makes a
+// wrong independence claim an error instead of a wrong witness.
+template <bool OWNED>
+static int witness_run(const Hasher& h, const u64* prog, size_t pc, size_t end, const u64* inputs, size_t n_inputs, u64* values, size_t n_values,
+                       uint16_t* owner, uint16_t me) {
     auto ok = [&](u64 v) { return v < n_values; };
-    while (pc < prog_words) {
+    auto rd = [&](u64 v) {
+        if constexpr (OWNED) { const uint16_t o = __atomic_load_n(&owner[v], __ATOMIC_RELAXED); return o == 0 || o == me; }
+        return true;
+    };
+    auto wr = [&](u64 v) {
+        if constexpr (OWNED) {
+            const uint16_t o = __atomic_load_n(&owner[v], __ATOMIC_RELAXED);
+            if (o != 0xFFFF && o != me) return false;
+            __atomic_store_n(&owner[v], me, __ATOMIC_RELAXED);
+        } else if (owner) owner[v] = me;
+        return true;
+    };
+    while (pc < end) {
         const u64 op = prog[pc];
         const u64* a = prog + pc + 1;
         switch (op) {
             case 0: {
-                if (pc + 8 > prog_words || !ok(a[0]) || !ok(a[1]) || !ok(a[2]) || !ok(a[3]) || a[4] >= GL_P || a[5] >= GL_P || a[6] >= GL_P) return GLP_E_INVALID;
+                if (pc + 8 > end || !ok(a[0]) || !ok(a[1]) || !ok(a[2]) || !ok(a[3]) || a[4] >= GL_P || a[5] >= GL_P || a[6] >= GL_P) return GLP_E_INVALID;
+                if (!rd(a[1]) || !rd(a[2]) || !rd(a[3]) || !wr(a[0])) return GLP_E_INVALID;
                 values[a[0]] = gl_add(gl_add(gl_mul(a[4], gl_mul(values[a[1]], values[a[2]])), gl_mul(a[5], values[a[3]])), a[6]);
                 pc += 8;
                 break;
             }
             case 1:
-                if (pc + 3 > prog_words || !ok(a[0]) || a[1] >= n_inputs || inputs[a[1]] >= GL_P) return GLP_E_INVALID;
+                if (pc + 3 > end || !ok(a[0]) || a[1] >= n_inputs || inputs[a[1]] >= GL_P || !wr(a[0])) return GLP_E_INVALID;
                 values[a[0]] = inputs[a[1]];
                 pc += 3;
                 break;
             case 2:
-                if (pc + 4 > prog_words || !ok(a[0]) || !ok(a[1]) || a[2] >= 64) return GLP_E_INVALID;
+                if (pc + 4 > end || !ok(a[0]) || !ok(a[1]) || a[2] >= 64 || !rd(a[1]) || !wr(a[0])) return GLP_E_INVALID;
                 values[a[0]] = (values[a[1]] >> a[2]) & 1ull;
                 pc += 4;
                 break;
             case 3:
-                if (pc + 3 > prog_words || !ok(a[0]) || !ok(a[1])) return GLP_E_INVALID;
+                if (pc + 3 > end || !ok(a[0]) || !ok(a[1]) || !rd(a[1]) || !wr(a[0])) return GLP_E_INVALID;
                 values[a[0]] = values[a[1]] ? gl_inv(values[a[1]]) : 0;
                 pc += 3;
                 break;
             case 4: {
-                if (pc + 5 > prog_words || !ok(a[0]) || !ok(a[1]) || !ok(a[2]) || !ok(a[3])) return GLP_E_INVALID;
+                if (pc + 5 > end || !ok(a[0]) || !ok(a[1]) || !ok(a[2]) || !ok(a[3]) || !rd(a[2]) || !rd(a[3]) || !wr(a[0]) || !wr(a[1])) return GLP_E_INVALID;
                 const gl_ext2 x{values[a[2]], values[a[3]]};
                 const gl_ext2 r = (x.a || x.b) ? ext_inv(x) : gl_ext2{0, 0};
                 values[a[0]] = r.a; values[a[1]] = r.b;
@@ -637,27 +651,75 @@ extern "C" int glp_witness_eval(const uint64_t* h_rc, const uint64_t* h_mds_circ
                 break;
             }
             case 5:
-                if (pc + 2 > prog_words || !ok(a[0])) return GLP_E_INVALID;
+                if (pc + 2 > end || !ok(a[0]) || !wr(a[0])) return GLP_E_INVALID;
                 values[a[0]] = 0;
                 pc += 2;
                 break;
             case 6: {
-                if (pc + 25 > prog_words) return GLP_E_INVALID;
+                if (pc + 25 > end) return GLP_E_INVALID;
                 u64 st[12];
-                for (int i = 0; i < 12; i++) { if (!ok(a[i]) || !ok(a[12 + i])) return GLP_E_INVALID; st[i] = values[a[12 + i]]; }
+                for (int i = 0; i < 12; i++) { if (!ok(a[i]) || !ok(a[12 + i]) || !rd(a[12 + i])) return GLP_E_INVALID; st[i] = values[a[12 + i]]; }
                 h.permute(st);
-                for (int i = 0; i < 12; i++) values[a[i]] = st[i];
+                for (int i = 0; i < 12; i++) { if (!wr(a[i])) return GLP_E_INVALID; values[a[i]] = st[i]; }
                 pc += 25;
                 break;
             }
             default: return GLP_E_INVALID;
         }
     }
+    return GLP_OK;
+}
+
+// seg_bounds (n_seg + 1 ascending word offsets on op boundaries, or NULL): the ops of [seg_bounds[k], seg_bounds[k+1]) are n_seg mutually
+// independent segments — each reads only what the prefix [0, seg_bounds[0]) or itself wrote — evaluated on up to n_threads host threads; the
+// tail [seg_bounds[n_seg], prog_words) runs after them.  The independence claim is CHECKED while running (GLP_E_INVALID when it is false).
+extern "C" int glp_witness_eval_mt(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint64_t* prog, size_t prog_words,
+                                   const uint64_t* inputs, size_t n_inputs, uint64_t* values, size_t n_values, const uint64_t* eq_pairs, size_t n_eq,
+                                   size_t* first_bad, const uint64_t* seg_bounds, size_t n_seg, uint32_t n_threads) {
+    Hasher h;
+    glp_challenger ch;
+    if (!prog || !values || (!inputs && n_inputs) || (!eq_pairs && n_eq) || !make_hasher_from(h_rc, h_mds_circ, h_mds_diag, h, ch)) return GLP_E_INVALID;
+    if (!seg_bounds || n_seg < 2 || n_threads < 2) {
+        const int rc = witness_run<false>(h, prog, 0, prog_words, inputs, n_inputs, values, n_values, nullptr, 0);
+        if (rc != GLP_OK) return rc;
+    } else {
+        if (n_seg >= 0xFFFE) return GLP_E_INVALID;
+        for (size_t k = 0; k <= n_seg; k++)
+            if (seg_bounds[k] > prog_words || (k && seg_bounds[k] < seg_bounds[k - 1])) return GLP_E_INVALID;
+        std::vector<uint16_t> owner(n_values, (uint16_t)0xFFFF);
+        int rc = witness_run<false>(h, prog, 0, (size_t)seg_bounds[0], inputs, n_inputs, values, n_values, owner.data(), 0);
+        if (rc != GLP_OK) return rc;
+        std::atomic<size_t> next{0};
+        std::atomic<int> status{GLP_OK};
+        auto worker = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= n_seg || status.load() != GLP_OK) return;
+                const int r = witness_run<true>(h, prog, (size_t)seg_bounds[k], (size_t)seg_bounds[k + 1], inputs, n_inputs, values, n_values, owner.data(),
+                                                (uint16_t)(k + 1));
+                if (r != GLP_OK) status.store(r);
+            }
+        };
+        const size_t nt = n_threads < n_seg ? n_threads : n_seg;
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nt; t++) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+        if (status.load() != GLP_OK) return status.load();
+        rc = witness_run<false>(h, prog, (size_t)seg_bounds[n_seg], prog_words, inputs, n_inputs, values, n_values, nullptr, 0);
+        if (rc != GLP_OK) return rc;
+    }
+    auto ok = [&](u64 v) { return v < n_values; };
     for (size_t k = 0; k < n_eq; k++) {
         if (!ok(eq_pairs[2 * k]) || !ok(eq_pairs[2 * k + 1])) return GLP_E_INVALID;
         if (values[eq_pairs[2 * k]] != values[eq_pairs[2 * k + 1]]) { if (first_bad) *first_bad = k; return GLP_E_REJECT; }
     }
     return GLP_OK;
+}
+extern "C" int glp_witness_eval(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint64_t* prog, size_t prog_words,
+                                const uint64_t* inputs, size_t n_inputs, uint64_t* values, size_t n_values, const uint64_t* eq_pairs, size_t n_eq,
+                                size_t* first_bad) {
+    return glp_witness_eval_mt(h_rc, h_mds_circ, h_mds_diag, prog, prog_words, inputs, n_inputs, values, n_values, eq_pairs, n_eq, first_bad, nullptr, 0, 1);
 }
 
 extern "C" int glp_plonk_proof_public_inputs(const uint8_t* proof, size_t len, uint64_t* h_out, size_t* n_words) {

@@ -15,7 +15,7 @@ needs extension-field arithmetic gadgets and the transcript in-circuit, listed i
 """
 import numpy as np
 
-from . import CIRCUIT_POSEIDON_GATE, P, PLONK_NCONST, POS_GATE_WIRES, PlonkCircuit  # noqa: F401
+from . import CIRCUIT_POSEIDON_GATE, P, PLONK_NCONST, POS_GATE_WIRES, DeviceBuffer, PlonkCircuit  # noqa: F401
 
 
 class CircuitBuilder:
@@ -33,6 +33,8 @@ class CircuitBuilder:
         self._consts = {}
         # the straight-line program that recomputes every variable from the free inputs (WitnessProgram / glp_witness_eval)
         self.prog = []                   # flat op words (encoding: csrc/verify.hip)
+        self._prefix = []                # ops of the constants: they run first, every segment may read them
+        self.seg_bounds = []             # offsets into prog: [start_0, end_0 = start_1, ..., end_last] of the independent segments
         self.input_tags = []             # per free input: caller's tag (e.g. (proof number, word position)) or None
         self.eq_pairs = []               # copy constraints between different variables
         self.word_checks = []            # ("const", tag, value) / ("var", tag, variable) / ("bits", tag, [bit variables]): facts about input
@@ -69,6 +71,21 @@ class CircuitBuilder:
         self.prog += (4, w0, w1, x0, x1)
         return w0, w1
 
+    def begin_segment(self):
+        """what is recorded until end_segment() depends only on constants and on itself (e.g. the verifier sub-circuit of ONE proof): the
+        witness evaluator may run segments on different host threads (glp_witness_eval_mt checks the claim while it runs).  Segments are
+        contiguous: nothing may be recorded between one segment's end and the next one's start."""
+        if self.seg_bounds and self.seg_bounds[-1] != len(self.prog):
+            raise ValueError("segments must follow each other directly")
+        if not self.seg_bounds:
+            self.seg_bounds.append(len(self.prog))
+        self._open = True
+
+    def end_segment(self):
+        assert getattr(self, "_open", False)
+        self._open = False
+        self.seg_bounds.append(len(self.prog))
+
     def _find(self, a):
         while self.parent[a] != a:
             self.parent[a] = self.parent[self.parent[a]]
@@ -102,9 +119,11 @@ class CircuitBuilder:
     def constant(self, k):
         k = int(k) % P
         if k not in self._consts:
+            main, self.prog = self.prog, self._prefix          # recorded into the prefix, wherever the constant is first used
             d = self._new(0)
             self.prog += (5, d)
             self._consts[k] = self.arith(0, 0, k, d, d, d)
+            self.prog = main
         return self._consts[k]
 
     def mul(self, x, y):
@@ -223,10 +242,27 @@ class WitnessProgram:
         self.public_vars = np.array(b.public, dtype=np.int64)
         self.roots = np.array([b._find(v) for v in range(len(b.parent))], dtype=np.int64)
         self.n_values = len(b.values)
-        self.prog = np.array(b.prog, dtype=np.uint64)
-        self.eq_pairs = np.array(b.eq_pairs, dtype=np.uint64)
+        self.prog = np.array(b._prefix + b.prog, dtype=np.uint64)
+        self.seg_bounds = np.array([len(b._prefix) + o for o in b.seg_bounds], dtype=np.uint64) if len(b.seg_bounds) > 2 else None
+        # cell -> variable map of the whole wire matrix (0xFFFFFFFF = zero); unused gate slots that must hold c2 read it from the tail of the
+        # value vector (device_witness appends those constants)
+        cell = np.full((W, n), 0xFFFFFFFF, dtype=np.uint32)
+        cell[self.cj, self.ci] = self.cv
+        for k, (j, i_, _) in enumerate(fixed):
+            cell[j, i_] = self.n_values + k
+        self.cell_index = cell
+        self.fixed_values = np.array([v for _, _, v in fixed], dtype=np.uint64)
+        self._dev = {}                               # prover -> resident (cell index, Poseidon row ids)
         self.input_tags = list(b.input_tags)
+        tags = self.input_tags
+        self._tag_list = np.array([t[0] for t in tags], dtype=np.int64) if tags and all(t is not None for t in tags) else None
+        self._tag_pos = np.array([t[1] for t in tags], dtype=np.int64) if self._tag_list is not None else None
+        self.eq_pairs = np.array(b.eq_pairs, dtype=np.uint64)
         self.word_checks = list(b.word_checks)
+        wc = self.word_checks
+        self._wc_const = tuple(np.array([f(c) for c in wc if c[0] == "const"], dtype=d) for f, d in
+                               ((lambda c: c[1][0], np.int64), (lambda c: c[1][1], np.int64), (lambda c: c[2], np.uint64)))
+        self._wc_other = [c for c in wc if c[0] != "const"]
         self.stats = {"rows": n, "poseidon_rows": len(b.pos_rows), "arith_gates": sum(len(r) for _, r in arith), "variables": self.n_values,
                       "inputs": len(self.input_tags)}
 
@@ -254,9 +290,11 @@ class WitnessProgram:
         sigma = prover.field_op("mul", ks[tgt_col], wp[tgt_row])
         return PlonkCircuit(prover, self.consts, sigma, cap_height=cap_height, n_wires=self.W, n_public=len(self.public_vars), poseidon=True)
 
-    def evaluate(self, poseidon_consts, inputs):
-        """every variable's value for new inputs (glp_witness_eval); ValueError when the inputs do not satisfy the circuit's copy constraints"""
+    def evaluate(self, poseidon_consts, inputs, threads=None):
+        """every variable's value for new inputs (glp_witness_eval_mt: the recorded segments on `threads` host threads, default all cores);
+        ValueError when the inputs do not satisfy the circuit's copy constraints"""
         import ctypes
+        import os
         from . import load_library
         lib = load_library()
         rc, circ, diag = (np.ascontiguousarray(a, dtype=np.uint64) for a in poseidon_consts)
@@ -265,9 +303,12 @@ class WitnessProgram:
             raise ValueError(f"{inp.size} inputs given, the program takes {len(self.input_tags)}")
         vals = np.zeros(self.n_values, dtype=np.uint64)
         bad = ctypes.c_size_t(0)
-        rcode = lib.glp_witness_eval(rc.ctypes.data, circ.ctypes.data, diag.ctypes.data, self.prog.ctypes.data, self.prog.size,
-                                     inp.ctypes.data if inp.size else None, inp.size, vals.ctypes.data, vals.size,
-                                     self.eq_pairs.ctypes.data if self.eq_pairs.size else None, self.eq_pairs.size // 2, ctypes.byref(bad))
+        sb = self.seg_bounds
+        nt = int(threads) if threads else min(32, os.cpu_count() or 1)
+        rcode = lib.glp_witness_eval_mt(rc.ctypes.data, circ.ctypes.data, diag.ctypes.data, self.prog.ctypes.data, self.prog.size,
+                                        inp.ctypes.data if inp.size else None, inp.size, vals.ctypes.data, vals.size,
+                                        self.eq_pairs.ctypes.data if self.eq_pairs.size else None, self.eq_pairs.size // 2, ctypes.byref(bad),
+                                        sb.ctypes.data if sb is not None else None, sb.size - 1 if sb is not None else 0, nt)
         if rcode == -7:
             raise ValueError(f"the inputs do not satisfy the circuit (copy constraint {bad.value} fails)")
         if rcode != 0:
@@ -278,19 +319,24 @@ class WitnessProgram:
         """the input vector of a program whose inputs were tagged (list number, word position) — e.g. the proofs a verifier circuit consumes —
         after checking the recorded facts about the non-input words (constants of the statement shape, the circuit's key)"""
         ws = [np.frombuffer(bytes(w), dtype="<u8") if isinstance(w, (bytes, bytearray)) else np.asarray(w, dtype=np.uint64) for w in word_lists]
-        for kind, tag, val in self.word_checks:
+        sizes = np.array([w.size for w in ws], dtype=np.int64)
+        off = np.concatenate(([0], np.cumsum(sizes)))[:-1]
+        flat = np.concatenate(ws) if ws else np.zeros(0, dtype=np.uint64)
+        ck, cpos, cval = self._wc_const
+        if ck.size:
+            if ck.max() >= len(ws) or np.any(cpos >= sizes[ck]) or np.any(flat[off[ck] + cpos] != cval):
+                raise ValueError("an input is not what this circuit was built for (a word fixed by the statement shape or the circuit's key differs)")
+        for kind, tag, val in self._wc_other:
             k, pos = tag
-            if pos >= ws[k].size or (kind == "const" and int(ws[k][pos]) != val):
-                raise ValueError(f"input {k}: word {pos} is not what this circuit was built for")
-        out = np.zeros(len(self.input_tags), dtype=np.uint64)
-        for i, tag in enumerate(self.input_tags):
-            if tag is None:
-                raise ValueError("this program has untagged inputs: pass the input vector itself")
-            k, pos = tag
-            if pos >= ws[k].size:
-                raise ValueError(f"input {k} is shorter than the program expects")
-            out[i] = ws[k][pos]
-        return out, ws
+            if k >= len(ws) or pos >= ws[k].size:
+                raise ValueError(f"input {k}: word {pos} is missing")
+        if not self.input_tags:
+            return np.zeros(0, dtype=np.uint64), ws
+        if self._tag_list is None:
+            raise ValueError("this program has untagged inputs: pass the input vector itself")
+        if self._tag_list.max() >= len(ws) or np.any(self._tag_pos >= sizes[self._tag_list]):
+            raise ValueError("an input is shorter than the program expects")
+        return flat[off[self._tag_list] + self._tag_pos], ws
 
     def check_words(self, vals, ws):
         """the recorded facts that tie non-input words to computed variables (redundant copies inside a proof)"""
@@ -302,15 +348,26 @@ class WitnessProgram:
                 raise ValueError(f"input {k}: word {pos} differs from the index the transcript derives")
 
     def device_witness(self, prover, vals):
-        """variable values -> wire matrix on the device, Poseidon rows' advice wires filled by the GPU; returns (buffer, public values)"""
+        """variable values -> wire matrix on the device: the values are uploaded (8 bytes per VARIABLE, not per cell) and placed by the resident
+        cell -> variable map (glp_gather_u64), Poseidon rows' advice wires filled by the GPU; returns (buffer, public values)"""
         n = 1 << self.log_n
-        wires = np.zeros((self.W, n), dtype=np.uint64)
-        for j, i, v in self.fixed:
-            wires[j, i] = v
-        wires[self.cj, self.ci] = vals[self.cv]
-        dw = prover.to_device(wires)
+        res = self._dev.get(id(prover))
+        if res is None:
+            res = self._dev[id(prover)] = prover.to_device(self.cell_index)
+        vals = np.ascontiguousarray(vals, dtype=np.uint64)
+        src = prover.to_device(np.concatenate((vals, self.fixed_values)) if self.fixed_values.size else vals)
+        dw = DeviceBuffer(prover, self.W * n * 8)
+        try:
+            prover.gather(dw, src, vals.size + self.fixed_values.size, res, self.W * n)
+        finally:
+            src.free()
         prover.poseidon_gate_fill_rows(dw, self.log_n, self.W, self.pos_row_ids)
         return dw, [int(v) for v in vals[self.public_vars]]
+
+    def release(self, prover=None):
+        """free the resident cell maps (of one prover, or all)"""
+        for key in [k for k in self._dev if prover is None or k == id(prover)]:
+            self._dev.pop(key).free()
 
 
 # ---- the Reduce step's aggregation tree -----------------------------------------------------------------------------------------

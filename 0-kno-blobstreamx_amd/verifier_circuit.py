@@ -557,8 +557,10 @@ class RecursionProgram:
         b = CircuitBuilder(prover)
         level = []
         for k, proof in enumerate(sample_proofs):
+            b.begin_segment()            # one proof's verifier depends on constants and on itself: the witness evaluator runs them in parallel
             out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height,
                                     poseidon_values if child_is_recursion else None, proof_id=k)
+            b.end_segment()
             for v in out["public"] + out["digest"]:
                 b.public_input(v)
             level.append(out["digest"])
@@ -588,4 +590,5 @@ class RecursionProgram:
             dw.free()
 
     def free(self):
+        self.program.release(self.prover)
         self.circuit.free()

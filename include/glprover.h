@@ -282,6 +282,17 @@ int glp_plonk_proof_digest(glp_ctx* ctx, const uint8_t* h_proof, size_t proof_le
 int glp_witness_eval(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint64_t* prog, size_t prog_words,
                      const uint64_t* inputs, size_t n_inputs, uint64_t* values, size_t n_values, const uint64_t* eq_pairs, size_t n_eq,
                      size_t* first_bad);
+/* ... on several host threads: seg_bounds = n_seg + 1 ascending word offsets (op boundaries); the ops of [seg_bounds[k], seg_bounds[k+1]) are
+ * n_seg mutually independent segments (each reads only what the prefix [0, seg_bounds[0]) or itself wrote — e.g. the verifier sub-circuits of
+ * the proofs a recursion node checks), run on up to n_threads threads; the tail after seg_bounds[n_seg] runs last.  The independence claim is
+ * checked while running: GLP_E_INVALID when a segment reads another segment's variable.  seg_bounds NULL / n_seg < 2 / n_threads < 2 = serial. */
+int glp_witness_eval_mt(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint64_t* prog, size_t prog_words,
+                        const uint64_t* inputs, size_t n_inputs, uint64_t* values, size_t n_values, const uint64_t* eq_pairs, size_t n_eq,
+                        size_t* first_bad, const uint64_t* seg_bounds, size_t n_seg, uint32_t n_threads);
+/* Witness placement on the device: d_dst[i] = d_index[i] == 0xFFFFFFFF ? 0 : d_src[d_index[i]], i < n (d_index: uint32, every other entry < n_src
+ * — checked on the device: an out-of-range entry writes 0 and the call returns GLP_E_INVALID).  With d_index = the circuit's cell -> variable map
+ * (resident, built once per circuit) and d_src = the evaluated variables, this lays out the wire matrix without a host-side copy of it. */
+int glp_gather_u64(glp_ctx* ctx, uint64_t* d_dst, const uint64_t* d_src, size_t n_src, const uint32_t* d_index, size_t n);
 int glp_plonk_proof_digest_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
                                 size_t proof_len, uint64_t* h_out4);
 

@@ -69,6 +69,50 @@ def test_c_evaluator_reproduces_the_builders_witness(oracle, which):
     assert prog.stats["inputs"] == len(inputs) and prog.stats["variables"] == len(vals)
 
 
+def test_segments_evaluate_in_parallel_and_false_independence_is_refused(oracle):
+    """two proofs' verifier sub-circuits recorded as independent segments: glp_witness_eval_mt on 4 threads reproduces the builder's values
+    (the constants both segments read were hoisted into the prefix); a segment that reads the other segment's variable is refused"""
+    rec, vc, _, _ = _mods()
+    consts = poseidon_consts("small")
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    with open(os.path.join(G, "proofs.json")) as f:
+        g = json.load(f)["plonk"]
+    proof = bytes.fromhex(g["proof"])
+    b = rec.CircuitBuilder(_oracle_prover(oracle))
+    digests = []
+    for k in range(3):
+        b.begin_segment()
+        digests.append(vc.verify_in_circuit(b, proof, g["circuit_cap"], g["queries"], g["pow_bits"], g["W"], proof_id=k)["digest"])
+        b.end_segment()
+    root = b.two_to_one(b.two_to_one(digests[0], digests[1])[:4], digests[2])            # the tail reads every segment
+    prog = b.program()
+    assert prog.seg_bounds is not None and prog.seg_bounds.size == 4
+    inputs, ws = prog.inputs_from_words([proof] * 3)
+    want = np.array(b.values, dtype=np.uint64)
+    for threads in (1, 4):
+        assert np.array_equal(prog.evaluate(consts, inputs, threads=threads), want)
+    assert [int(want[v]) for v in root] == [b.value(v) for v in root]
+    # a false claim: segment 2 multiplies a variable that segment 1 computed
+    b2 = rec.CircuitBuilder(_oracle_prover(oracle))
+    b2.begin_segment()
+    x = b2.var(3, tag=(0, 0))
+    y = b2.mul(x, x)
+    b2.end_segment()
+    b2.begin_segment()
+    z = b2.var(5, tag=(0, 1))
+    b2.mul(z, y)
+    b2.end_segment()
+    b2.begin_segment()
+    b2.mul(b2.var(7, tag=(0, 2)), b2.constant(9))
+    b2.end_segment()
+    p2 = b2.program()
+    with pytest.raises(ValueError):
+        p2.evaluate(consts, [3, 5, 7], threads=2)
+    assert int(p2.evaluate(consts, [3, 5, 7], threads=1)[y]) == 9                          # serially the same program is fine
+    with pytest.raises(ValueError):
+        b2.begin_segment(); b2.end_segment(); b2.var(1); b2.begin_segment()                 # a gap between segments
+
+
 def test_sha256_program_hashes_new_messages(oracle):
     """the SHA-256 gadget recorded for one 64-byte message, replayed by the C evaluator for others"""
     rec, _, gd, _ = _mods()
