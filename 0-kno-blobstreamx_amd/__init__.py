@@ -186,6 +186,7 @@ def load_library():
                                             ctypes.POINTER(ctypes.c_size_t)]),
         "glp_witness_eval_mt": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
                                                ctypes.POINTER(ctypes.c_size_t), _vp, ctypes.c_size_t, ctypes.c_uint32]),
+        "glp_poseidon_permute_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t]),
         "glp_gather_u64": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
         "glp_comm_unique_id": (ctypes.c_int, [_vp]),
         "glp_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
@@ -266,6 +267,17 @@ def plonk_verify_host(constants, proof, circuit_cap, min_queries=DEFAULT_MIN_QUE
     pp, pn, keep = _public_arg(public)
     extra = (cap.ctypes.data if cap is not None else None, cap.size if cap is not None else 0, pp, pn)
     return _host_verify("glp_plonk_verify_host_ex", constants, proof, extra, min_queries, min_pow_bits)
+
+
+def poseidon_permute_host(consts, states):
+    """Poseidon permutation of [n][12] states on the host (glp_poseidon_permute_host); consts = (rc[360], mds_circ[12], mds_diag[12])"""
+    lib = load_library()
+    rc, circ, diag = (np.ascontiguousarray(a, dtype=np.uint64) for a in consts)
+    s = np.array(states, dtype=np.uint64).reshape(-1, 12)
+    code = lib.glp_poseidon_permute_host(rc.ctypes.data, circ.ctypes.data, diag.ctypes.data, s.ctypes.data, s.shape[0])
+    if code != 0:
+        raise GlpError(f"glp_poseidon_permute_host -> {code}")
+    return s
 
 
 def proof_digest_host(constants, proof):
@@ -540,6 +552,13 @@ class Prover:
         diag = np.ascontiguousarray(diag, dtype=np.uint64)
         self._chk(self.lib.glp_set_poseidon_constants(self.ctx, rc.ctypes.data, rc.size, circ.ctypes.data, diag.ctypes.data),
                   "glp_set_poseidon_constants")
+        self._pos_consts = (rc.copy(), circ.copy(), diag.copy())
+
+    def poseidon_permute_host(self, states):
+        """the same permutation by the library's host arithmetic (no device round trip: what the circuit builder hashes single states with)"""
+        if getattr(self, "_pos_consts", None) is None:
+            raise GlpError("poseidon_permute_host: set_poseidon_constants first")
+        return poseidon_permute_host(self._pos_consts, states)
 
     def poseidon_permute_(self, d_states, n):
         self._chk(self.lib.glp_poseidon_permute(self.ctx, _ptr(d_states), n), "glp_poseidon_permute")

@@ -586,6 +586,20 @@ extern "C" int glp_plonk_proof_digest_host(const uint64_t* h_rc, const uint64_t*
     return proof_digest(h, proof, len, h_out4);
 }
 
+// the permutation on the host (n states of 12 words, in place): what the circuit builder and a light client hash with
+extern "C" int glp_poseidon_permute_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, uint64_t* states, size_t n) {
+    Hasher h;
+    glp_challenger ch;
+    if ((!states && n) || !make_hasher_from(h_rc, h_mds_circ, h_mds_diag, h, ch)) return GLP_E_INVALID;
+    for (size_t i = 0; i < n; i++) {
+        u64 st[12];
+        for (int k = 0; k < 12; k++) { if (states[12 * i + k] >= GL_P) return GLP_E_INVALID; st[k] = states[12 * i + k]; }
+        h.permute(st);
+        for (int k = 0; k < 12; k++) states[12 * i + k] = st[k];
+    }
+    return GLP_OK;
+}
+
 // ---- witness evaluator for circuits recorded by the host builder (recursion.py::WitnessProgram) -------------------------------------
 // A recorded circuit is a straight-line program over its variables: arithmetic gates, free inputs, bit extractions, inverses, Poseidon
 // permutations — each op defines NEW variables from earlier ones, so one forward pass computes the whole witness.  The dependency chain is

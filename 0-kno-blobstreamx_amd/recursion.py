@@ -146,9 +146,10 @@ class CircuitBuilder:
         self.public.append(v)
 
     def poseidon(self, ins):
-        """one permutation row; ins: 12 variables -> 12 output variables (values from the GPU's own permutation)"""
+        """one permutation row; ins: 12 variables -> 12 output variables (values from the library's own permutation)"""
         assert len(ins) == 12
-        out = self.prover.poseidon_permute(np.array([[self.values[v] for v in ins]], dtype=np.uint64))[0]
+        permute = getattr(self.prover, "poseidon_permute_host", None) or self.prover.poseidon_permute      # host arithmetic: no device round trip
+        out = permute(np.array([[self.values[v] for v in ins]], dtype=np.uint64))[0]
         outs = [self._new(int(v)) for v in out]
         self.prog += (6, *outs, *ins)
         self.pos_rows.append((list(ins), outs))
@@ -238,33 +239,71 @@ class WitnessProgram:
         self.cj, self.ci, self.cv = np.array(cj, dtype=np.int64), np.array(ci, dtype=np.int64), np.array(cv, dtype=np.int64)
         if self.cj.size and int(self.cj.max()) >= R:
             raise ValueError("a variable sits on an unrouted wire")
-        self.fixed = fixed
+        self.fixed = np.array(fixed, dtype=np.uint64).reshape(-1, 3)
+        self.pos_row_ids = np.array(self.pos_row_ids, dtype=np.uint32)
         self.public_vars = np.array(b.public, dtype=np.int64)
         self.roots = np.array([b._find(v) for v in range(len(b.parent))], dtype=np.int64)
         self.n_values = len(b.values)
         self.prog = np.array(b._prefix + b.prog, dtype=np.uint64)
         self.seg_bounds = np.array([len(b._prefix) + o for o in b.seg_bounds], dtype=np.uint64) if len(b.seg_bounds) > 2 else None
-        # cell -> variable map of the whole wire matrix (0xFFFFFFFF = zero); unused gate slots that must hold c2 read it from the tail of the
-        # value vector (device_witness appends those constants)
-        cell = np.full((W, n), 0xFFFFFFFF, dtype=np.uint32)
-        cell[self.cj, self.ci] = self.cv
-        for k, (j, i_, _) in enumerate(fixed):
-            cell[j, i_] = self.n_values + k
-        self.cell_index = cell
-        self.fixed_values = np.array([v for _, _, v in fixed], dtype=np.uint64)
-        self._dev = {}                               # prover -> resident (cell index, Poseidon row ids)
-        self.input_tags = list(b.input_tags)
-        tags = self.input_tags
-        self._tag_list = np.array([t[0] for t in tags], dtype=np.int64) if tags and all(t is not None for t in tags) else None
-        self._tag_pos = np.array([t[1] for t in tags], dtype=np.int64) if self._tag_list is not None else None
+        tags = b.input_tags
+        if tags and all(t is not None for t in tags):
+            self.input_tags = np.array(tags, dtype=np.int64).reshape(-1, 2)
+        else:
+            self.input_tags = None if tags else np.zeros((0, 2), dtype=np.int64)
+        self.n_inputs = len(tags)
         self.eq_pairs = np.array(b.eq_pairs, dtype=np.uint64)
-        self.word_checks = list(b.word_checks)
-        wc = self.word_checks
-        self._wc_const = tuple(np.array([f(c) for c in wc if c[0] == "const"], dtype=d) for f, d in
-                               ((lambda c: c[1][0], np.int64), (lambda c: c[1][1], np.int64), (lambda c: c[2], np.uint64)))
-        self._wc_other = [c for c in wc if c[0] != "const"]
+        # facts about input words checked outside the circuit: (list, position, value) / (list, position, variable) / bit lists
+        wc = b.word_checks
+        self.wc_const = np.array([(c[1][0], c[1][1], c[2]) for c in wc if c[0] == "const"], dtype=np.uint64).reshape(-1, 3)
+        self.wc_var = np.array([(c[1][0], c[1][1], c[2]) for c in wc if c[0] == "var"], dtype=np.int64).reshape(-1, 3)
+        bits = [c for c in wc if c[0] == "bits"]
+        self.wc_bits = np.array([(c[1][0], c[1][1], len(c[2])) for c in bits], dtype=np.int64).reshape(-1, 3)
+        self.wc_bit_vars = np.array([v for c in bits for v in c[2]], dtype=np.int64)
         self.stats = {"rows": n, "poseidon_rows": len(b.pos_rows), "arith_gates": sum(len(r) for _, r in arith), "variables": self.n_values,
-                      "inputs": len(self.input_tags)}
+                      "inputs": self.n_inputs}
+        self._finish()
+
+    _SAVED = ("consts", "cj", "ci", "cv", "fixed", "pos_row_ids", "public_vars", "roots", "prog", "eq_pairs", "wc_const", "wc_var", "wc_bits", "wc_bit_vars")
+
+    def _finish(self):
+        """what is derived from the recorded arrays: the cell -> variable map of the whole wire matrix (0xFFFFFFFF = zero; an unused gate slot
+        that must hold c2 reads it from the tail of the value vector, where device_witness appends those constants)"""
+        n = 1 << self.log_n
+        cell = np.full((self.W, n), 0xFFFFFFFF, dtype=np.uint32)
+        cell[self.cj, self.ci] = self.cv
+        if self.fixed.shape[0]:
+            cell[self.fixed[:, 0].astype(np.int64), self.fixed[:, 1].astype(np.int64)] = self.n_values + np.arange(self.fixed.shape[0])
+        self.cell_index = cell
+        self.fixed_values = np.ascontiguousarray(self.fixed[:, 2])
+        self._dev = {}                               # prover -> resident cell map
+
+    def save(self, path):
+        """the recorded circuit as one .npz of plain arrays (nothing executable): a later process loads it instead of running the builder again —
+        the 'build once, prove many times' split of the reference's circuit artifacts"""
+        meta = np.array([self.W, self.R, self.log_n, self.n_values, self.n_inputs, -1 if self.input_tags is None else 0], dtype=np.int64)
+        arrays = {k: getattr(self, k) for k in self._SAVED}
+        arrays["input_tags"] = self.input_tags if self.input_tags is not None else np.zeros((0, 2), dtype=np.int64)
+        arrays["seg_bounds"] = self.seg_bounds if self.seg_bounds is not None else np.zeros(0, dtype=np.uint64)
+        arrays["stats"] = np.array([self.stats[k] for k in ("rows", "poseidon_rows", "arith_gates", "variables", "inputs")], dtype=np.int64)
+        np.savez(path, meta=meta, **arrays)
+
+    @classmethod
+    def load(cls, path):
+        self = object.__new__(cls)
+        with np.load(path, allow_pickle=False) as z:
+            self.W, self.R, self.log_n, self.n_values, self.n_inputs, tagged = (int(v) for v in z["meta"])
+            for k in cls._SAVED:
+                setattr(self, k, z[k])
+            self.input_tags = None if tagged < 0 else z["input_tags"]
+            self.seg_bounds = z["seg_bounds"] if z["seg_bounds"].size else None
+            self.stats = dict(zip(("rows", "poseidon_rows", "arith_gates", "variables", "inputs"), (int(v) for v in z["stats"])))
+        n = 1 << self.log_n
+        if (self.consts.shape != (PLONK_NCONST, n) or self.roots.size != self.n_values or not (self.cj.size == self.ci.size == self.cv.size)
+                or (self.cv.size and (self.cv.max() >= self.n_values or self.cj.max() >= self.R or self.ci.max() >= n))):
+            raise ValueError("not a recorded circuit of this format")
+        self._finish()
+        return self
 
     def setup(self, prover, cap_height=1):
         """commit the circuit (constants + sigma): one cycle per copy class over its cells, sigma values by the GPU's field multiplication"""
@@ -299,8 +338,8 @@ class WitnessProgram:
         lib = load_library()
         rc, circ, diag = (np.ascontiguousarray(a, dtype=np.uint64) for a in poseidon_consts)
         inp = np.ascontiguousarray(inputs, dtype=np.uint64)
-        if inp.size != len(self.input_tags):
-            raise ValueError(f"{inp.size} inputs given, the program takes {len(self.input_tags)}")
+        if inp.size != self.n_inputs:
+            raise ValueError(f"{inp.size} inputs given, the program takes {self.n_inputs}")
         vals = np.zeros(self.n_values, dtype=np.uint64)
         bad = ctypes.c_size_t(0)
         sb = self.seg_bounds
@@ -322,30 +361,31 @@ class WitnessProgram:
         sizes = np.array([w.size for w in ws], dtype=np.int64)
         off = np.concatenate(([0], np.cumsum(sizes)))[:-1]
         flat = np.concatenate(ws) if ws else np.zeros(0, dtype=np.uint64)
-        ck, cpos, cval = self._wc_const
-        if ck.size:
-            if ck.max() >= len(ws) or np.any(cpos >= sizes[ck]) or np.any(flat[off[ck] + cpos] != cval):
-                raise ValueError("an input is not what this circuit was built for (a word fixed by the statement shape or the circuit's key differs)")
-        for kind, tag, val in self._wc_other:
-            k, pos = tag
-            if k >= len(ws) or pos >= ws[k].size:
-                raise ValueError(f"input {k}: word {pos} is missing")
-        if not self.input_tags:
+        def at(tab):
+            """the words a table's (list, position) columns name; ValueError when one is missing"""
+            k, pos = tab[:, 0].astype(np.int64), tab[:, 1].astype(np.int64)
+            if k.size and (k.max() >= len(ws) or np.any(pos >= sizes[k])):
+                raise ValueError("an input is shorter than this circuit expects")
+            return flat[off[k] + pos]
+        if np.any(at(self.wc_const) != self.wc_const[:, 2]):
+            raise ValueError("an input is not what this circuit was built for (a word fixed by the statement shape or the circuit's key differs)")
+        at(self.wc_var), at(self.wc_bits)
+        if self.n_inputs == 0:
             return np.zeros(0, dtype=np.uint64), ws
-        if self._tag_list is None:
+        if self.input_tags is None:
             raise ValueError("this program has untagged inputs: pass the input vector itself")
-        if self._tag_list.max() >= len(ws) or np.any(self._tag_pos >= sizes[self._tag_list]):
-            raise ValueError("an input is shorter than the program expects")
-        return flat[off[self._tag_list] + self._tag_pos], ws
+        return at(self.input_tags), ws
 
     def check_words(self, vals, ws):
-        """the recorded facts that tie non-input words to computed variables (redundant copies inside a proof)"""
-        for kind, tag, val in self.word_checks:
-            k, pos = tag
-            if kind == "var" and int(ws[k][pos]) != int(vals[val]):
+        """the recorded facts that tie non-input words to computed variables (redundant copies inside a proof, query indices)"""
+        for k, pos, var in self.wc_var:
+            if int(ws[k][pos]) != int(vals[var]):
                 raise ValueError(f"input {k}: word {pos} differs from the value the circuit derives")
-            if kind == "bits" and int(ws[k][pos]) != sum(int(vals[bv]) << j for j, bv in enumerate(val)):
+        o = 0
+        for k, pos, nb in self.wc_bits:
+            if int(ws[k][pos]) != sum(int(b) << j for j, b in enumerate(vals[self.wc_bit_vars[o:o + nb]])):
                 raise ValueError(f"input {k}: word {pos} differs from the index the transcript derives")
+            o += nb
 
     def device_witness(self, prover, vals):
         """variable values -> wire matrix on the device: the values are uploaded (8 bytes per VARIABLE, not per cell) and placed by the resident

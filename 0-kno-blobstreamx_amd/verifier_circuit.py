@@ -575,6 +575,22 @@ class RecursionProgram:
     def key(self):
         return self.circuit.cap()
 
+    def save(self, path):
+        """the recorded circuit as an .npz of plain arrays (WitnessProgram.save): build once, load in every prover process"""
+        self.program.save(path)
+
+    @classmethod
+    def load(cls, prover, path, poseidon_values):
+        """a RecursionProgram from a saved recording: no builder run; the circuit is committed again on this prover (its key is a function of
+        the recording alone, so it equals the key of the process that recorded it)"""
+        from .recursion import WitnessProgram
+        self = object.__new__(cls)
+        self.prover, self.consts = prover, poseidon_values
+        self.program = WitnessProgram.load(path)
+        self.circuit = self.program.setup(prover)
+        self.stats = dict(self.program.stats)
+        return self
+
     def witness(self, proofs):
         inputs, ws = self.program.inputs_from_words(proofs)
         vals = self.program.evaluate(self.consts, inputs)

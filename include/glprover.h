@@ -293,6 +293,8 @@ int glp_witness_eval_mt(const uint64_t* h_rc, const uint64_t* h_mds_circ, const 
  * — checked on the device: an out-of-range entry writes 0 and the call returns GLP_E_INVALID).  With d_index = the circuit's cell -> variable map
  * (resident, built once per circuit) and d_src = the evaluated variables, this lays out the wire matrix without a host-side copy of it. */
 int glp_gather_u64(glp_ctx* ctx, uint64_t* d_dst, const uint64_t* d_src, size_t n_src, const uint32_t* d_index, size_t n);
+/* the Poseidon permutation on the host: n states of 12 canonical words, in place (same constants arguments as the host verifiers) */
+int glp_poseidon_permute_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, uint64_t* states, size_t n);
 int glp_plonk_proof_digest_host(const uint64_t* h_rc, const uint64_t* h_mds_circ, const uint64_t* h_mds_diag, const uint8_t* h_proof,
                                 size_t proof_len, uint64_t* h_out4);
 

@@ -39,5 +39,12 @@ for rep in range(2):
     dwv.free()
     names = ["inputs_from_words", "evaluate", "check_words", "device_witness", "prove"]
     out[f"rep{rep}"] = {n: round(b - a, 4) for n, a, b in zip(names, t, t[1:])}
+t0 = time.perf_counter()
+rp.save("/tmp/rp_rec.npz")
+t1 = time.perf_counter()
+rp2 = vcm.RecursionProgram.load(pr, "/tmp/rp_rec.npz", (rc, circ, diag))
+t2 = time.perf_counter()
+out["save_seconds"], out["load_and_commit_seconds"], out["file_mb"] = round(t1 - t0, 3), round(t2 - t1, 3), round(os.path.getsize("/tmp/rp_rec.npz") / 2**20, 1)
+out["loaded_key_matches"] = bool(np.array_equal(rp2.key(), rp.key()))
 out["verified"] = bool(rp.circuit.verify(proof, 28, 16, public=pub))
 print(json.dumps(out))

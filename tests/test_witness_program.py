@@ -69,7 +69,7 @@ def test_c_evaluator_reproduces_the_builders_witness(oracle, which):
     assert prog.stats["inputs"] == len(inputs) and prog.stats["variables"] == len(vals)
 
 
-def test_segments_evaluate_in_parallel_and_false_independence_is_refused(oracle):
+def test_segments_evaluate_in_parallel_and_false_independence_is_refused(oracle, tmp_path):
     """two proofs' verifier sub-circuits recorded as independent segments: glp_witness_eval_mt on 4 threads reproduces the builder's values
     (the constants both segments read were hoisted into the prefix); a segment that reads the other segment's variable is refused"""
     rec, vc, _, _ = _mods()
@@ -91,6 +91,13 @@ def test_segments_evaluate_in_parallel_and_false_independence_is_refused(oracle)
     want = np.array(b.values, dtype=np.uint64)
     for threads in (1, 4):
         assert np.array_equal(prog.evaluate(consts, inputs, threads=threads), want)
+    # the recording survives a round trip through its file form (plain arrays, loaded without pickle)
+    prog.save(str(tmp_path / "rec.npz"))
+    again = rec.WitnessProgram.load(str(tmp_path / "rec.npz"))
+    i2, ws2 = again.inputs_from_words([proof] * 3)
+    assert np.array_equal(i2, inputs) and np.array_equal(again.evaluate(consts, i2, threads=2), want)
+    again.check_words(want, ws2)
+    assert np.array_equal(again.cell_index, prog.cell_index) and np.array_equal(again.consts, prog.consts) and again.stats == prog.stats
     assert [int(want[v]) for v in root] == [b.value(v) for v in root]
     # a false claim: segment 2 multiplies a variable that segment 1 computed
     b2 = rec.CircuitBuilder(_oracle_prover(oracle))
@@ -148,7 +155,7 @@ def _witness_for(circ, rng):
 
 
 @pytest.mark.gpu
-def test_recursion_program_recorded_once_proves_other_batches(prover, oracle, pkg):
+def test_recursion_program_recorded_once_proves_other_batches(prover, oracle, pkg, tmp_path):
     """the recursion circuit is laid down ONCE (Python builder) from a sample batch of leaf proofs; other batches — proofs of the same leaf
     circuit for other witnesses — are proved through the recorded program (C evaluator + GPU), with the same key; a bad proof is refused"""
     rec, vc, _, mr = _mods()
@@ -181,5 +188,12 @@ def test_recursion_program_recorded_once_proves_other_batches(prover, oracle, pk
         rp.prove(bad, 8, 4)
     with pytest.raises(ValueError):
         rp.prove(batches[1][:1] + [batches[1][1][:-8]], 8, 4)
+    # build once, load elsewhere: the saved recording commits to the same key and proves
+    rp.save(str(tmp_path / "rp.npz"))
+    rp2 = vc.RecursionProgram.load(prover, str(tmp_path / "rp.npz"), consts)
+    assert np.array_equal(rp2.key(), rp.key())
+    proof2, public2 = rp2.prove(batches[1], 8, 4)
+    assert prover.plonk_verify(proof2, rp.key(), 8, 4, public=public2), prover.last_reject
+    rp2.free()
     rp.free()
     ck.free()
