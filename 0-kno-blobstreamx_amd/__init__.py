@@ -58,6 +58,10 @@ class CircuitShape(ctypes.Structure):
 
 
 PLONK_NCONST = 6                 # constant columns: q_arith, c0, c1, c2, q_pi, q_pos
+PLONK_NCONST_SHA = 10            # ... + q_she, q_sha, q_shw, q_add for circuits with SHA-256 rows
+CIRCUIT_SHA_GATES = 2
+SHA_GATE_WIRES = 144
+SHA_ROW_E, SHA_ROW_A, SHA_ROW_W, SHA_ROW_ADD = 0, 1, 2, 3
 CIRCUIT_POSEIDON_GATE = 1
 POS_GATE_WIRES = 130
 
@@ -182,6 +186,7 @@ def load_library():
         "glp_poseidon_gate_fill_rows": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint32]),
         "glp_plonk_proof_digest": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
         "glp_plonk_proof_digest_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+        "glp_sha_gate_fill_rows": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, ctypes.c_uint32]),
         "glp_witness_eval": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
                                             ctypes.POINTER(ctypes.c_size_t)]),
         "glp_witness_eval_mt": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
@@ -743,6 +748,21 @@ class Prover:
         finally:
             dr.free()
 
+    def sha_gate_fill_rows(self, d_wires, log_n, n_wires, rows, kinds):
+        """witness generation for SHA rows: the bit wires 12..143 of row rows[k] (kind kinds[k]) from its routed words, in place on the device"""
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        k = np.ascontiguousarray(kinds, dtype=np.uint32)
+        assert r.size == k.size
+        if r.size == 0:
+            return
+        dr, dk = self.to_device(r), self.to_device(k)
+        try:
+            self._chk(self.lib.glp_sha_gate_fill_rows(self.ctx, _ptr(d_wires), log_n, n_wires, dr.ptr, dk.ptr, r.size), "glp_sha_gate_fill_rows")
+            self.sync()
+        finally:
+            dr.free()
+            dk.free()
+
     def gather(self, d_dst, d_src, n_src, d_index, n):
         """d_dst[i] = d_src[d_index[i]] (0xFFFFFFFF -> 0), all on the device: witness placement (glp_gather_u64)"""
         self._chk(self.lib.glp_gather_u64(self.ctx, _ptr(d_dst), _ptr(d_src), n_src, _ptr(d_index), n), "glp_gather_u64")
@@ -824,20 +844,22 @@ class PlonkCircuit:
     prove(wires, public) returns the proof bytes.  DESIGN.md §3.6.
       consts: [6][n] = (q_arith, c0, c1, c2, q_pi, q_pos) row values — or the round-1 form [3][n] = (q, c0, c1)
       sigmas: [n_routed][n];  n_wires: total wire columns (default: all routed);  n_public: rows 0..n_public-1 expose wire 0
-      poseidon: q_pos rows carry a permutation (needs n_wires >= 130, n_routed >= 24)"""
+      poseidon: q_pos rows carry a permutation (needs n_wires >= 130, n_routed >= 24)
+      sha: SHA-256 rows (consts [10][n]: + q_she, q_sha, q_shw, q_add; n_wires >= 144, n_routed >= 16)"""
 
-    def __init__(self, prover, consts, sigmas, rate_bits=3, cap_height=4, n_wires=None, n_public=0, poseidon=False):
+    def __init__(self, prover, consts, sigmas, rate_bits=3, cap_height=4, n_wires=None, n_public=0, poseidon=False, sha=False):
         self.prover = prover
         c = np.ascontiguousarray(consts, dtype=np.uint64)
         s = np.ascontiguousarray(sigmas, dtype=np.uint64)
         self.n_routed, n = s.shape
         self.n_wires = self.n_routed if n_wires is None else int(n_wires)
         self.n_public = int(n_public)
-        self.flags = CIRCUIT_POSEIDON_GATE if poseidon else 0
+        self.flags = (CIRCUIT_POSEIDON_GATE if poseidon else 0) | (CIRCUIT_SHA_GATES if sha else 0)
         self.log_n = n.bit_length() - 1
-        assert 1 << self.log_n == n and c.shape in ((3, n), (PLONK_NCONST, n))
-        if c.shape[0] == 3:
-            c = np.concatenate([c, np.zeros((3, n), dtype=np.uint64)])
+        nc = PLONK_NCONST_SHA if sha else PLONK_NCONST
+        assert 1 << self.log_n == n and c.shape in ((3, n), (PLONK_NCONST, n), (nc, n))
+        if c.shape[0] < nc:
+            c = np.concatenate([c, np.zeros((nc - c.shape[0], n), dtype=np.uint64)])
         dc, ds = prover.to_device(c), prover.to_device(s)
         h = _vp()
         shape = CircuitShape(self.log_n, self.n_wires, self.n_routed, self.n_public, rate_bits, cap_height, self.flags)

@@ -70,7 +70,7 @@ extern "C" int glp_plonk_setup_ex(glp_ctx* c, const glp_circuit_shape* sh, const
     // Poseidon row degree 8, so the quotient has degree < 8n — 8 chunks, evaluated on the 8n-point coset; a larger blow-up
     // would only make every commitment bigger.  W <= 160 = 20 chunks of wires: what the K7 register budget was sized for.
     if (log_n < 3 || log_n > 24 || n_wires == 0 || n_wires % 8 || n_wires > 160 || R == 0 || R % 8 || R > n_wires || sh->rate_bits != 3 ||
-        sh->cap_height > 12 || sh->n_public > (1u << log_n) || (sh->flags & ~GLP_CIRCUIT_POSEIDON_GATE)) {
+        sh->cap_height > 12 || sh->n_public > (1u << log_n) || (sh->flags & ~(GLP_CIRCUIT_POSEIDON_GATE | GLP_CIRCUIT_SHA_GATES))) {
         glp_set_err(c, "glp_plonk_setup: unsupported shape (W %% 8 == 0, W <= 160, routed %% 8 == 0, routed <= W, rate_bits == 3, n_public <= n)");
         return GLP_E_INVALID;
     }
@@ -78,7 +78,12 @@ extern "C" int glp_plonk_setup_ex(glp_ctx* c, const glp_circuit_shape* sh, const
         glp_set_err(c, "glp_plonk_setup: a Poseidon-gate circuit needs >= %d wires, >= 24 of them routed", GLP_POS_GATE_WIRES);
         return GLP_E_INVALID;
     }
+    if ((sh->flags & GLP_CIRCUIT_SHA_GATES) && (n_wires < GLP_SHA_GATE_WIRES || R < 16)) {
+        glp_set_err(c, "glp_plonk_setup: a SHA-row circuit needs >= %d wires, >= 16 of them routed", GLP_SHA_GATE_WIRES);
+        return GLP_E_INVALID;
+    }
     if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set"); return GLP_E_STATE; }
+    const u32 n_const = (u32)glp_plonk_n_const(sh->flags);
     std::unique_ptr<glp_plonk_circuit> ck(new glp_plonk_circuit(c));
     ck->log_n = log_n; ck->W = n_wires; ck->R = R; ck->n_public = sh->n_public; ck->flags = sh->flags;
     ck->rate_bits = sh->rate_bits; ck->cap_h = sh->cap_height; ck->shift = 7;
@@ -92,12 +97,12 @@ extern "C" int glp_plonk_setup_ex(glp_ctx* c, const glp_circuit_shape* sh, const
     GLP_HIPCHK(c, hipMemcpyAsync(ck->ks.p, ck->h_ks.data(), R * 8, hipMemcpyHostToDevice, c->stream));
     GLP_HIPCHK(c, ck->sigma_vals.alloc((size_t)R * n * 8));
     GLP_HIPCHK(c, hipMemcpyAsync(ck->sigma_vals.p, d_sigma_vals, (size_t)R * n * 8, hipMemcpyDeviceToDevice, c->stream));
-    // batch 0 = [the GLP_PLONK_NCONST constant columns, sigma_0 .. sigma_{R-1}]
-    u64* pre_vals = (u64*)glp_pool_alloc(c, (size_t)(GLP_PLONK_NCONST + R) * n * 8);
+    // batch 0 = [the constant columns (6, or 10 with SHA rows), sigma_0 .. sigma_{R-1}]
+    u64* pre_vals = (u64*)glp_pool_alloc(c, (size_t)(n_const + R) * n * 8);
     if (!pre_vals) return GLP_E_NOMEM;
-    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals, d_const_vals, (size_t)GLP_PLONK_NCONST * n * 8, hipMemcpyDeviceToDevice, c->stream));
-    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals + GLP_PLONK_NCONST * n, d_sigma_vals, (size_t)R * n * 8, hipMemcpyDeviceToDevice, c->stream));
-    int rc = commit_values(c, pre_vals, GLP_PLONK_NCONST + R, log_n, ck->rate_bits, ck->cap_h, ck->pre);
+    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals, d_const_vals, (size_t)n_const * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals + (size_t)n_const * n, d_sigma_vals, (size_t)R * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    int rc = commit_values(c, pre_vals, n_const + R, log_n, ck->rate_bits, ck->cap_h, ck->pre);
     if (rc) return rc;
     // 1 / (x - 1) on the LDE domain
     const u64* w_lo = nullptr; const u64* w_hi = nullptr;
@@ -141,6 +146,21 @@ extern "C" int glp_poseidon_gate_fill_rows(glp_ctx* c, uint64_t* d_wire_vals, ui
     if (n_rows == 0) return GLP_OK;
     hipLaunchKernelGGL(glp_poseidon_gate_fill_kernel<0>, dim3((n_rows + 63) / 64), dim3(64), 0, c->stream, d_wire_vals, 1ull << log_n, d_rows, n_rows,
                        c->hash->d_consts);
+    GLP_HIPCHK(c, hipGetLastError());
+    return GLP_OK;
+}
+
+// witness generation for SHA rows: the bit wires 12..143 of every listed row from its routed words 0..11 (plonk_gates.h)
+extern "C" int glp_sha_gate_fill_rows(glp_ctx* c, uint64_t* d_wire_vals, uint32_t log_n, uint32_t n_wires, const uint32_t* d_rows,
+                                      const uint32_t* d_kinds, uint32_t n_rows) {
+    if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
+    if (!d_wire_vals || ((!d_rows || !d_kinds) && n_rows) || log_n > 24 || n_wires < GLP_SHA_GATE_WIRES) {
+        glp_set_err(c, "glp_sha_gate_fill_rows: bad argument");
+        return GLP_E_INVALID;
+    }
+    if (n_rows == 0) return GLP_OK;
+    hipLaunchKernelGGL(glp_sha_gate_fill_kernel<0>, dim3((n_rows + 63) / 64), dim3(64), 0, c->stream, d_wire_vals, 1ull << log_n, d_rows, d_kinds, n_rows);
     GLP_HIPCHK(c, hipGetLastError());
     return GLP_OK;
 }
@@ -198,7 +218,8 @@ static int public_input_lde(glp_ctx* c, glp_plonk_circuit* ck, const u64* h_publ
 }
 
 static u32 n_constraints(const glp_plonk_circuit* ck) {
-    return 2 + 3 * (ck->R / GLP_PLONK_CHUNK) + ((ck->flags & GLP_CIRCUIT_POSEIDON_GATE) ? GLP_POS_GATE_CONSTRAINTS : 0);
+    return 2 + 3 * (ck->R / GLP_PLONK_CHUNK) + ((ck->flags & GLP_CIRCUIT_POSEIDON_GATE) ? GLP_POS_GATE_CONSTRAINTS : 0) +
+           ((ck->flags & GLP_CIRCUIT_SHA_GATES) ? GLP_SHA_GATE_CONSTRAINTS : 0);
 }
 
 // ---- K7: quotient evaluations on the LDE domain (bit-reversed order) for given challenges -> quot_rev [NCHAL][N] ----
@@ -217,7 +238,7 @@ static int quotient_evals(glp_ctx* c, glp_plonk_circuit* ck, const u64* wires_ld
     int rc = glp_ntt_table(c, (int)log_N, 0, &wN_lo, &wN_hi);
     if (rc) return rc;
     GlpQuotientArgs qa;
-    qa.consts = ck->pre.lde.u(); qa.sigmas = ck->pre.lde.u() + GLP_PLONK_NCONST * N; qa.wires = wires_lde; qa.zs = zs_lde; qa.pi = pi_lde;
+    qa.consts = ck->pre.lde.u(); qa.sigmas = ck->pre.lde.u() + (u64)glp_plonk_n_const(ck->flags) * N; qa.wires = wires_lde; qa.zs = zs_lde; qa.pi = pi_lde;
     qa.ks = ck->ks.u();
     qa.log_n = log_n; qa.rate_bits = rb; qa.W = ck->W; qa.R = ck->R; qa.n_con = n_con;
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) { qa.beta[t] = beta[t]; qa.gamma[t] = gamma[t]; }
@@ -233,6 +254,11 @@ static int quotient_evals(glp_ctx* c, glp_plonk_circuit* ck, const u64* wires_ld
     else
         hipLaunchKernelGGL(glp_quotient_kernel<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa);
     GLP_HIPCHK(c, hipGetLastError());
+    if (ck->flags & GLP_CIRCUIT_SHA_GATES) {
+        const u32 first_con = n_con - GLP_SHA_GATE_CONSTRAINTS;
+        hipLaunchKernelGGL(glp_quotient_sha_kernel<0>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa, first_con);
+        GLP_HIPCHK(c, hipGetLastError());
+    }
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));      // apow (host) and d_apow die with this frame
     return GLP_OK;
 }

@@ -260,6 +260,46 @@ __global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
     }
 }
 
+// ---- K7s: the SHA-row block of the constraint sum (GLP_CIRCUIT_SHA_GATES circuits), added to what K7 wrote ----------------
+// consts then has GLP_PLONK_NCONST_SHA rows; the block's alpha powers start at first_con = 2 + 3M (+ 118 with Poseidon rows).
+// A kernel of its own: the 64 bit wires it keeps live (X and Y groups, for the rotations) would push K7 into spills, and circuits
+// without SHA rows do not pay for it.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) glp_quotient_sha_kernel(GlpQuotientArgs a, u32 first_con) {
+    const u32 log_N = a.log_n + a.rate_bits;
+    const u64 N = 1ull << log_N;
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    u64 e = 0;
+    for (u32 b = 0; b < log_N; b++) e |= ((i >> b) & 1ull) << (log_N - 1 - b);
+    const u64 zhi = a.zh_inv[e & ((1ull << a.rate_bits) - 1)];
+    const u64 q[4] = {a.consts[6 * N + i], a.consts[7 * N + i], a.consts[8 * N + i], a.consts[9 * N + i]};
+    const u64 c2 = a.consts[3 * N + i];
+    u64 acc[GLP_PLONK_NCHAL];
+    for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) acc[t] = 0;
+    u32 k = 0;
+    const u64* ap0 = a.alpha_pow + first_con;
+    glp_sha_gate_constraints<GlpGateBase>([&](int j) -> u64 { return a.wires[(u64)j * N + i]; }, q, c2, [&](u64 con) {
+        for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) acc[t] = gl_add(acc[t], gl_mul(ap0[(u64)t * a.n_con + k], con));
+        k++;
+    });
+    for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) a.out[(u64)t * N + i] = gl_add(a.out[(u64)t * N + i], gl_mul(acc[t], zhi));
+}
+
+// ---- SHA-row witness: for each listed row of the listed kind, the bit wires 12..143 from the routed words 0..11 (plonk_gates.h) ----
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(64) glp_sha_gate_fill_kernel(u64* __restrict__ wires, u64 n, const u32* __restrict__ rows, const u32* __restrict__ kinds,
+                                                              u32 n_rows) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rows) return;
+    const u64 row = rows[k];
+    if (row >= n || kinds[k] > 3) return;
+    u64 r[12], bits[132];
+    for (int j = 0; j < 12; j++) r[j] = wires[(u64)j * n + row];
+    glp_sha_gate_fill((int)kinds[k], r, bits);
+    for (int j = 0; j < 132; j++) wires[(u64)(12 + j) * n + row] = bits[j];
+}
+
 // ---- Poseidon-row witness: for each listed row, wires 12..129 from wires 0..11 (plonk_gates.h) ----
 // wires: [W][n] values on the trace domain; rows: n_rows row indices; consts: rc[360], circ[12], diag[12] (device)
 template <int UNUSED = 0>

@@ -358,7 +358,7 @@ bool make_hasher_from(const u64* rc, const u64* circ, const u64* diag, Hasher& h
 }
 
 // sum_idx alpha_t^idx * C_idx at zeta for challenge t (the constraint list of plonk_kernels.cuh / DESIGN.md §3.6), extension field
-gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 R, bool poseidon, const u64* pos_consts, const std::vector<u64>& ks, const u64* beta,
+gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 R, bool poseidon, bool sha, const u64* pos_consts, const std::vector<u64>& ks, const u64* beta,
                        const u64* gamma, const u64* alpha, const gl_ext2* consts, const gl_ext2* sigmas, const gl_ext2* wires, const gl_ext2* zs,
                        const gl_ext2* z_next, gl_ext2 pi_at_x) {
     typedef GlpGateExt O;
@@ -399,6 +399,13 @@ gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 R, bool poseidon
                                              pacc = gl_ext_add(pacc, gl_ext_scale(con, ap));
                                          });
         acc = gl_ext_add(acc, gl_ext_mul(q_pos, pacc));
+    }
+    if (sha) {                                   // consts then has GLP_PLONK_NCONST_SHA entries; the constraints arrive selector-weighted
+        const gl_ext2 qs[4] = {consts[6], consts[7], consts[8], consts[9]};
+        glp_sha_gate_constraints<O>([&](int j) -> gl_ext2 { return wires[j]; }, qs, c2, [&](gl_ext2 con) {
+            ap = gl_mul(ap, alpha[t]);
+            acc = gl_ext_add(acc, gl_ext_scale(con, ap));
+        });
     }
     return acc;
 }
@@ -453,10 +460,12 @@ static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, co
     if (!take_obs(8, &hd)) return rj.fail("truncated");
     const u64 tag = hd[0], log_n = hd[1], W = hd[2], R = hd[3], rb = hd[4], cap_h = hd[5], n_pub = hd[6], flags = hd[7];
     if (tag != PLONK_TAG || rb != 3 || W % 8 || W < 8 || W > 160 || R % 8 || R < 8 || R > W || log_n < 3 || log_n > 24 ||
-        n_pub > (1ull << log_n) || (flags & ~(u64)GLP_CIRCUIT_POSEIDON_GATE))
+        n_pub > (1ull << log_n) || (flags & ~(u64)(GLP_CIRCUIT_POSEIDON_GATE | GLP_CIRCUIT_SHA_GATES)))
         return rj.fail("bad plonk header");
-    const bool poseidon = (flags & GLP_CIRCUIT_POSEIDON_GATE) != 0;
+    const bool poseidon = (flags & GLP_CIRCUIT_POSEIDON_GATE) != 0, sha = (flags & GLP_CIRCUIT_SHA_GATES) != 0;
     if (poseidon && (W < GLP_POS_GATE_WIRES || R < 24)) return rj.fail("bad plonk header");
+    if (sha && (W < GLP_SHA_GATE_WIRES || R < 16)) return rj.fail("bad plonk header");
+    const u64 n_const = (u64)glp_plonk_n_const((u32)flags);
     const u64 n = 1ull << log_n;
     const u32 log_N = (u32)(log_n + rb), M = (u32)(R / CHUNK);
     const u64* pub;
@@ -482,7 +491,7 @@ static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, co
     int rc = fri_verify(rj, h, ch, rd, false, min_queries, min_pow_bits, 1, fi);
     if (rc != GLP_OK) return rc;
     // the FRI part must be about exactly these commitments, shapes and points
-    const u64 want_polys[4] = {GLP_PLONK_NCONST + R, W, (u64)NCHAL * M, (u64)NCHAL << rb};
+    const u64 want_polys[4] = {n_const + R, W, (u64)NCHAL * M, (u64)NCHAL << rb};
     if (fi.nb != 4 || fi.log_n != log_n || fi.rb != rb || fi.cap0 != (cap_h < log_N ? cap_h : log_N)) return rj.fail("FRI statement does not match the circuit shape");
     const u64* want_caps[4] = {cap_pre, cap_wires, cap_zs, cap_q};
     for (int b = 0; b < 4; b++) {
@@ -512,7 +521,7 @@ static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, co
     gl_ext2 z_next[NCHAL];
     for (u32 t = 0; t < NCHAL; t++) z_next[t] = zs_next[t * M];
     for (u32 t = 0; t < NCHAL; t++) {
-        const gl_ext2 lhs = constraint_sum(t, fi.zeta, zn, n, (u32)R, poseidon, h.consts.data(), ks, beta, gamma, alpha, pre, pre + GLP_PLONK_NCONST,
+        const gl_ext2 lhs = constraint_sum(t, fi.zeta, zn, n, (u32)R, poseidon, sha, h.consts.data(), ks, beta, gamma, alpha, pre, pre + n_const,
                                            wires, zs, z_next, pi_z);
         gl_ext2 tz{0, 0}, zp{1, 0};
         for (u32 cc = 0; cc < (1u << rb); cc++) {
@@ -608,6 +617,8 @@ extern "C" int glp_poseidon_permute_host(const uint64_t* h_rc, const uint64_t* h
 //   2 BIT    w x k              w = bit k of canonical x        3 INV   w x          w = 1/x (0 -> 0)
 //   4 EINV   w0 w1 x0 x1        (w0,w1) = 1/(x0 + x1 X)          5 ZERO  w            w = 0
 //   6 POSEIDON o0..o11 i0..i11  outputs = permutation(inputs)
+//   7 SHA_E T1 e_new e f g h d w K    8 SHA_A a_new a b c T1    9 SHA_W w_new w16 w15 w7 w2    10 ADD32 s x y      (the SHA rows of plonk_gates.h;
+//     an input that is not a 32-bit word -> GLP_E_REJECT with *first_bad = (size_t)-1: no witness satisfies the row)
 // eq_pairs: 2*n_eq variable indices that must hold equal values (the circuit's copy constraints between DIFFERENT variables): the first
 // violated pair is reported through *first_bad and the call returns GLP_E_REJECT — the witness does not satisfy the circuit (e.g. the
 // verifier circuit was fed a proof that does not verify).
@@ -678,6 +689,51 @@ static int witness_run(const Hasher& h, const u64* prog, size_t pc, size_t end, 
                 pc += 25;
                 break;
             }
+            // SHA-256 rows (plonk_gates.h): every input must be a 32-bit word (T1: < 2^35) — anything else cannot satisfy the row
+            case 7: {   // SHA_E  T1 e_new | e f g h d w | K
+                if (pc + 10 > end || a[8] > 0xFFFFFFFFull) return GLP_E_INVALID;
+                for (int i = 0; i < 8; i++) if (!ok(a[i])) return GLP_E_INVALID;
+                for (int i = 2; i < 8; i++) if (!rd(a[i])) return GLP_E_INVALID;
+                u64 v[6];
+                for (int i = 0; i < 6; i++) { v[i] = values[a[2 + i]]; if (v[i] >> 32) return GLP_E_REJECT; }
+                if (!wr(a[0]) || !wr(a[1])) return GLP_E_INVALID;
+                const u64 t1 = v[3] + glp_sha_S1(v[0]) + glp_sha_ch(v[0], v[1], v[2]) + a[8] + v[5];
+                values[a[0]] = t1;
+                values[a[1]] = (v[4] + t1) & 0xFFFFFFFFull;
+                pc += 10;
+                break;
+            }
+            case 8: {   // SHA_A  a_new | a b c T1
+                if (pc + 6 > end) return GLP_E_INVALID;
+                for (int i = 0; i < 5; i++) if (!ok(a[i])) return GLP_E_INVALID;
+                for (int i = 1; i < 5; i++) if (!rd(a[i])) return GLP_E_INVALID;
+                const u64 va = values[a[1]], vb = values[a[2]], vc = values[a[3]], t1 = values[a[4]];
+                if ((va | vb | vc) >> 32 || t1 >> 35) return GLP_E_REJECT;
+                if (!wr(a[0])) return GLP_E_INVALID;
+                values[a[0]] = (t1 + glp_sha_S0(va) + glp_sha_maj(va, vb, vc)) & 0xFFFFFFFFull;
+                pc += 6;
+                break;
+            }
+            case 9: {   // SHA_W  w_new | w16 w15 w7 w2
+                if (pc + 6 > end) return GLP_E_INVALID;
+                for (int i = 0; i < 5; i++) if (!ok(a[i])) return GLP_E_INVALID;
+                for (int i = 1; i < 5; i++) if (!rd(a[i])) return GLP_E_INVALID;
+                const u64 w16 = values[a[1]], w15 = values[a[2]], w7 = values[a[3]], w2 = values[a[4]];
+                if ((w16 | w15 | w7 | w2) >> 32) return GLP_E_REJECT;
+                if (!wr(a[0])) return GLP_E_INVALID;
+                values[a[0]] = (w16 + glp_sha_s0(w15) + w7 + glp_sha_s1(w2)) & 0xFFFFFFFFull;
+                pc += 6;
+                break;
+            }
+            case 10: {  // ADD32  s | x y
+                if (pc + 4 > end || !ok(a[0]) || !ok(a[1]) || !ok(a[2]) || !rd(a[1]) || !rd(a[2])) return GLP_E_INVALID;
+                const u64 x = values[a[1]], y = values[a[2]];
+                if ((x | y) >> 32) return GLP_E_REJECT;
+                if (!wr(a[0])) return GLP_E_INVALID;
+                values[a[0]] = (x + y) & 0xFFFFFFFFull;
+                pc += 4;
+                break;
+            }
             default: return GLP_E_INVALID;
         }
     }
@@ -693,6 +749,7 @@ extern "C" int glp_witness_eval_mt(const uint64_t* h_rc, const uint64_t* h_mds_c
     Hasher h;
     glp_challenger ch;
     if (!prog || !values || (!inputs && n_inputs) || (!eq_pairs && n_eq) || !make_hasher_from(h_rc, h_mds_circ, h_mds_diag, h, ch)) return GLP_E_INVALID;
+    if (first_bad) *first_bad = (size_t)-1;
     if (!seg_bounds || n_seg < 2 || n_threads < 2) {
         const int rc = witness_run<false>(h, prog, 0, prog_words, inputs, n_inputs, values, n_values, nullptr, 0);
         if (rc != GLP_OK) return rc;

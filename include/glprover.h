@@ -192,6 +192,19 @@ void glp_free_host(void* p);
 #define GLP_PLONK_NCONST 6
 #define GLP_CIRCUIT_POSEIDON_GATE 1u
 #define GLP_POS_GATE_WIRES 130
+/*   SHA-256 rows (flag)     four more constant columns select the row kind — [6] q_she [7] q_sha [8] q_shw [9] q_add, so d_const_vals is
+ *                           [GLP_PLONK_NCONST_SHA][n] for such a circuit — and one compression is 64 E rows (e-half of a round: T1 and the new e;
+ *                           K_t in the row's c2), 64 A rows (the new a), 48 W rows (message schedule) and 2 ADD rows (the feed-forward; four
+ *                           additions mod 2^32 per row, also the 32-bit range check).  Words are routed wires 0..11; wires 12..143 are the
+ *                           row's own bit decompositions (fill them with glp_sha_gate_fill_rows); 140 constraints of degree <= 4; layouts
+ *                           and equations: csrc/plonk_gates.h */
+#define GLP_PLONK_NCONST_SHA 10
+#define GLP_CIRCUIT_SHA_GATES 2u
+#define GLP_SHA_GATE_WIRES 144
+#define GLP_SHA_ROW_E 0
+#define GLP_SHA_ROW_A 1
+#define GLP_SHA_ROW_W 2
+#define GLP_SHA_ROW_ADD 3
 typedef struct {
     uint32_t log_n;        /* 3..24 */
     uint32_t n_wires;      /* multiple of 8, <= 160 */
@@ -199,7 +212,8 @@ typedef struct {
     uint32_t n_public;     /* <= 2^log_n */
     uint32_t rate_bits;    /* 3 */
     uint32_t cap_height;   /* <= 12 */
-    uint32_t flags;        /* GLP_CIRCUIT_POSEIDON_GATE: needs n_wires >= GLP_POS_GATE_WIRES and n_routed >= 24 */
+    uint32_t flags;        /* GLP_CIRCUIT_POSEIDON_GATE: needs n_wires >= GLP_POS_GATE_WIRES and n_routed >= 24;
+                              GLP_CIRCUIT_SHA_GATES: n_wires >= GLP_SHA_GATE_WIRES, n_routed >= 16, ten constant columns */
 } glp_circuit_shape;
 typedef struct glp_plonk_circuit glp_plonk_circuit;
 int glp_plonk_setup_ex(glp_ctx* ctx, const glp_circuit_shape* shape, const uint64_t* d_const_vals, const uint64_t* d_sigma_vals,
@@ -220,6 +234,10 @@ int glp_plonk_prove(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wire_
  * are computed from its wires 0..11, in place in d_wire_vals [n_wires][2^log_n].  Stream-ordered. */
 int glp_poseidon_gate_fill_rows(glp_ctx* ctx, uint64_t* d_wire_vals, uint32_t log_n, uint32_t n_wires, const uint32_t* d_rows,
                                 uint32_t n_rows);
+/* witness generation for SHA rows: for row d_rows[k] of kind d_kinds[k] (GLP_SHA_ROW_*; both device, u32) the bit wires 12..143 are computed
+ * from the routed words in wires 0..11 (inputs AND outputs of the row: the witness program computed the outputs), in place.  Stream-ordered. */
+int glp_sha_gate_fill_rows(glp_ctx* ctx, uint64_t* d_wire_vals, uint32_t log_n, uint32_t n_wires, const uint32_t* d_rows,
+                           const uint32_t* d_kinds, uint32_t n_rows);
 
 /* Parity hook for rows a6 / a7: the prover's intermediate stages for CALLER-CHOSEN challenges, so the HIP output can be
  * compared directly with an independent restatement (tests/plonk_ref.py) and not only through accepted proofs.

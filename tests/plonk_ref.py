@@ -15,6 +15,16 @@ TAG = 0x32304B4C504C4747       # "GGLPLK02"
 FLAG_POSEIDON = 1
 POS_WIRES = 130
 POS_CONSTRAINTS = 118
+FLAG_SHA = 2
+NCONST_SHA = 10                # ... + q_she, q_sha, q_shw, q_add
+SHA_WIRES = 144
+SHA_CONSTRAINTS = 140
+SHA_E, SHA_A, SHA_W, SHA_ADD = 0, 1, 2, 3
+M32 = 0xFFFFFFFF
+
+
+def n_const(flags):
+    return NCONST_SHA if flags & FLAG_SHA else NCONST
 
 
 def ks_of(W):
@@ -126,12 +136,94 @@ def poseidon_constraints(F, wires, consts):
     return out
 
 
+# ---- SHA-256 rows: words on wires 0..11, four 32-bit groups of bit wires at 12/44/76/108, carries at 140..143 ------
+def _rotr(x, r):
+    return ((x >> r) | (x << (32 - r))) & M32
+
+
+def sha_row(kind, words, k_const=0):
+    """the 144 wire values of a SHA row from its INPUT words (ints < 2^32; T1 may reach 2^35): outputs, bit groups and carries computed here.
+    E: words = (e, f, g, h, d, w);  A: (a, b, c, T1);  W: (w16, w15, w7, w2);  ADD: up to four (x, y) pairs, flattened."""
+    r = [0] * 12
+    if kind == SHA_E:
+        e, f, g, h, d, w = words
+        t1 = h + (_rotr(e, 6) ^ _rotr(e, 11) ^ _rotr(e, 25)) + ((e & f) ^ (~e & g & M32)) + k_const + w
+        e_new = (d + t1) & M32
+        r[:8] = [e, f, g, h, d, w, t1, e_new]
+        groups, carry = [e, f, g, e_new], (d + t1) >> 32
+    elif kind == SHA_A:
+        a, b, c, t1 = words
+        tot = t1 + (_rotr(a, 2) ^ _rotr(a, 13) ^ _rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c))
+        r[:5] = [a, b, c, t1, tot & M32]
+        groups, carry = [a, b, c, tot & M32], tot >> 32
+    elif kind == SHA_W:
+        w16, w15, w7, w2 = words
+        tot = w16 + (_rotr(w15, 7) ^ _rotr(w15, 18) ^ (w15 >> 3)) + w7 + (_rotr(w2, 17) ^ _rotr(w2, 19) ^ (w2 >> 10))
+        r[:5] = [w16, w15, w7, w2, tot & M32]
+        groups, carry = [w15, w2, 0, tot & M32], tot >> 32
+    else:
+        groups, carry = [0, 0, 0, 0], 0
+        for k in range(len(words) // 2):
+            x, y = words[2 * k], words[2 * k + 1]
+            r[3 * k:3 * k + 3] = [x, y, (x + y) & M32]
+            groups[k] = (x + y) & M32
+            carry |= ((x + y) >> 32) << k
+    bits = [(g >> i) & 1 for g in groups for i in range(32)] + [(carry >> k) & 1 for k in range(4)]
+    return r + bits
+
+
+def sha_constraints(F, wires, q4, c2):
+    """the 140 selector-weighted constraint values of the SHA block at one point; wires = the row's first 144 wire values, q4 = (q_she, q_sha,
+    q_shw, q_add), c2 = the row's c2 constant — all F elements"""
+    qE, qA, qW, qD = q4
+    q_any = F.add(F.add(qE, qA), F.add(qW, qD))
+    out = [F.mul(q_any, F.sub(F.mul(b, b), b)) for b in wires[12:144]]
+    X, Y, Z, N, cw = wires[12:44], wires[44:76], wires[76:108], wires[108:140], wires[140:144]
+
+    def pack(bits):
+        acc = F.zero
+        for i, b in enumerate(bits):
+            acc = F.add(acc, F.scale(b, 1 << i))
+        return acc
+
+    xor = lambda a, b: F.sub(F.add(a, b), F.scale(F.mul(a, b), 2))
+    px, py, pz, pn = pack(X), pack(Y), pack(Z), pack(N)
+    ch = pack([F.add(z, F.mul(x, F.sub(y, z))) for x, y, z in zip(X, Y, Z)])
+    maj = pack([F.add(F.mul(x, y), F.mul(z, xor(x, y))) for x, y, z in zip(X, Y, Z)])
+    S1 = pack([xor(xor(X[(i + 6) % 32], X[(i + 11) % 32]), X[(i + 25) % 32]) for i in range(32)])
+    S0 = pack([xor(xor(X[(i + 2) % 32], X[(i + 13) % 32]), X[(i + 22) % 32]) for i in range(32)])
+    s0 = pack([xor(xor(X[(i + 7) % 32], X[(i + 18) % 32]), X[i + 3]) if i + 3 < 32 else xor(X[(i + 7) % 32], X[(i + 18) % 32]) for i in range(32)])
+    s1 = pack([xor(xor(Y[(i + 17) % 32], Y[(i + 19) % 32]), Y[i + 10]) if i + 10 < 32 else xor(Y[(i + 17) % 32], Y[(i + 19) % 32]) for i in range(32)])
+    w = wires
+    two32 = 1 << 32
+    car2 = F.add(cw[0], F.scale(cw[1], 2))
+    car3 = F.add(car2, F.scale(cw[2], 4))
+    mix = lambda e, a, ww, d: F.add(F.add(F.mul(qE, e), F.mul(qA, a)), F.add(F.mul(qW, ww), F.mul(qD, d)))
+    zero = F.zero
+    out.append(mix(F.sub(px, w[0]), F.sub(px, w[0]), F.sub(px, w[1]), F.sub(px, w[2])))
+    out.append(mix(F.sub(py, w[1]), F.sub(py, w[1]), F.sub(py, w[3]), F.sub(py, w[5])))
+    out.append(mix(F.sub(pz, w[2]), F.sub(pz, w[2]), zero, F.sub(pz, w[8])))
+    out.append(mix(F.sub(pn, w[7]), F.sub(pn, w[4]), F.sub(pn, w[4]), F.sub(pn, w[11])))
+    e4 = F.sub(w[6], F.add(F.add(F.add(w[3], S1), F.add(ch, c2)), w[5]))
+    a4 = F.sub(F.add(w[4], F.scale(car3, two32)), F.add(F.add(w[3], S0), maj))
+    w4 = F.sub(F.add(w[4], F.scale(car2, two32)), F.add(F.add(w[0], s0), F.add(w[2], s1)))
+    d4 = F.sub(F.add(w[2], F.scale(cw[0], two32)), F.add(w[0], w[1]))
+    out.append(mix(e4, a4, w4, d4))
+    e5 = F.sub(F.add(w[7], F.scale(car3, two32)), F.add(w[4], w[6]))
+    d5 = F.sub(F.add(w[5], F.scale(cw[1], two32)), F.add(w[3], w[4]))
+    out.append(mix(e5, zero, zero, d5))
+    out.append(F.mul(qD, F.sub(F.add(w[8], F.scale(cw[2], two32)), F.add(w[6], w[7]))))
+    out.append(F.mul(qD, F.sub(F.add(w[11], F.scale(cw[3], two32)), F.add(w[9], w[10]))))
+    assert len(out) == SHA_CONSTRAINTS
+    return out
+
+
 def int_consts(consts):
     return tuple([int(v) for v in a] for a in consts)
 
 
 # ---- circuit generator -------------------------------------------------------------------------------------------------------
-def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, poseidon_rows=(), consts=None, public_values=None):
+def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, poseidon_rows=(), consts=None, public_values=None, sha_rows=()):
     """random satisfiable instance.  Returns a dict: consts [6][n], sigmas [R][n], wires [W][n] (uint64), public (list of ints),
     shape fields.  poseidon_rows: row indices that carry a permutation (needs W >= 130, R >= 24 and the Poseidon constants);
     n_public: rows 0..n_public-1 expose wire 0 as a public input (public_values: what those cells must hold; default random)."""
@@ -139,16 +231,21 @@ def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, posei
     R = W if n_routed is None else n_routed
     G = R // 4
     pos = set(int(r) for r in poseidon_rows)
+    sha = {int(r): int(rng.integers(0, 4)) for r in sha_rows}          # row -> kind
+    assert not (pos & set(sha)) and (not sha or (W >= SHA_WIRES and R >= 16))
     if pos:
         assert W >= POS_WIRES and R >= 24 and consts is not None
         consts = int_consts(consts)
     rnd = lambda: int(rng.integers(0, 1 << 62)) * 4 % P
-    q = [0 if i in pos else (1 if rng.random() < 0.8 else 0) for i in range(n)]
+    q = [0 if (i in pos or i in sha) else (1 if rng.random() < 0.8 else 0) for i in range(n)]
     c0 = [rnd() for _ in range(n)]
     c1 = [rnd() for _ in range(n)]
     c2 = [rnd() if rng.random() < 0.5 else 0 for _ in range(n)]
     q_pi = [1 if i < n_public else 0 for i in range(n)]
     q_pos = [1 if i in pos else 0 for i in range(n)]
+    q_sha = [[1 if sha.get(i) == kind else 0 for i in range(n)] for kind in range(4)]
+    for i in sha:
+        c2[i] = int(rng.integers(0, 1 << 32))                          # K_t of an E row (ignored by the other kinds)
     wires = [[0] * n for _ in range(W)]
     parent = {}
 
@@ -178,7 +275,23 @@ def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, posei
             wires[j][i] = rnd()
         cells.append((j, i))
 
+    r32 = lambda: int(rng.integers(0, 1 << 32))
     for i in range(n):
+        if i in sha:
+            kind = sha[i]
+            if kind == SHA_E:
+                row = sha_row(kind, [r32() for _ in range(6)], c2[i])
+            elif kind == SHA_A:
+                row = sha_row(kind, [r32(), r32(), r32(), int(rng.integers(0, 5 << 32))])
+            elif kind == SHA_W:
+                row = sha_row(kind, [r32() for _ in range(4)])
+            else:
+                row = sha_row(kind, [r32() for _ in range(2 * int(rng.integers(0, 5)))])
+            for j in range(W):
+                wires[j][i] = row[j] if j < SHA_WIRES else rnd()
+                if j < min(R, 12):
+                    cells.append((j, i))                  # words: may be copied FROM
+            continue
         if i in pos:
             for j in range(12):
                 fresh_or_copy(j, i)                       # inputs: free cells (copies of earlier outputs chain permutations)
@@ -216,8 +329,8 @@ def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, posei
             jj, ii = members[(a + 1) % len(members)]
             sigma[j][i] = ks[jj] * wp[ii] % P
     to_np = lambda rows: np.array(rows, dtype=np.uint64)
-    return {"log_n": log_n, "W": W, "R": R, "n_public": n_public, "flags": FLAG_POSEIDON if pos else 0,
-            "consts": to_np([q, c0, c1, c2, q_pi, q_pos]), "sigmas": to_np(sigma), "wires": to_np(wires),
+    return {"log_n": log_n, "W": W, "R": R, "n_public": n_public, "flags": (FLAG_POSEIDON if pos else 0) | (FLAG_SHA if sha else 0),
+            "consts": to_np([q, c0, c1, c2, q_pi, q_pos] + (q_sha if sha else [])), "sigmas": to_np(sigma), "wires": to_np(wires),
             "public": [wires[0][i] for i in range(n_public)], "pos_consts": consts}
 
 
@@ -281,7 +394,7 @@ def constraint_sum(t, x, n, R, ks, beta, gamma, alpha, consts, sigmas, wires, zs
         xn = F.mul(xn, xn)
     inv = fv.einv if ext else (lambda v: pow(v, P - 2, P))
     l1 = F.mul(F.sub(xn, one), inv(F.scale(F.sub(x, one), n % P)))
-    q, c0, c1, c2, q_pi, q_pos = consts
+    q, c0, c1, c2, q_pi, q_pos = consts[:6]
     acc = F.mul(l1, F.sub(zs[t * M], one))
     ap = alpha[t]
     acc = F.add(acc, F.scale(F.sub(F.mul(q_pi, wires[0]), pi_at_x), ap))
@@ -307,6 +420,10 @@ def constraint_sum(t, x, n, R, ks, beta, gamma, alpha, consts, sigmas, wires, zs
             ap = ap * alpha[t] % P
             pacc = F.add(pacc, F.scale(con, ap))
         acc = F.add(acc, F.mul(q_pos, pacc))
+    if len(consts) == NCONST_SHA:
+        for con in sha_constraints(F, wires, consts[6:10], c2):
+            ap = ap * alpha[t] % P
+            acc = F.add(acc, F.scale(con, ap))
     return acc
 
 
@@ -357,8 +474,10 @@ def verify_plonk(proof_bytes, oracle, pos_consts=None, public=None):
 
     tag, log_n, W, R, rb, cap_h, n_pub, flags = take(8)
     if tag != TAG or rb != 3 or W % 8 or not (8 <= W <= 160) or R % 8 or not (8 <= R <= W) or not (3 <= log_n <= 24) or n_pub > (1 << log_n) \
-            or flags & ~FLAG_POSEIDON:
+            or flags & ~(FLAG_POSEIDON | FLAG_SHA):
         raise fv.VerifyError("bad plonk header")
+    if flags & FLAG_SHA and (W < SHA_WIRES or R < 16):
+        raise fv.VerifyError("SHA-row circuit: bad shape")
     poseidon = bool(flags & FLAG_POSEIDON)
     if poseidon and (W < POS_WIRES or R < 24 or pos_consts is None):
         raise fv.VerifyError("Poseidon-gate circuit: bad shape or constants not supplied")
@@ -380,7 +499,7 @@ def verify_plonk(proof_bytes, oracle, pos_consts=None, public=None):
     info = fv.parse_and_verify(None, oracle, challenger=ch, words=words, pos=pos)
     # the FRI part must be about exactly these commitments, shapes and points
     flat = lambda cap: [v for d in cap for v in d]
-    if info["n_polys"] != [NCONST + R, W, NCHAL * M, NCHAL << rb] or info["log_n"] != log_n or info["rate_bits"] != rb:
+    if info["n_polys"] != [n_const(flags) + R, W, NCHAL * M, NCHAL << rb] or info["log_n"] != log_n or info["rate_bits"] != rb:
         raise fv.VerifyError("FRI statement does not match the circuit shape")
     if [flat(c) for c in info["caps"]] != [cap_pre, cap_wires, cap_zs, cap_q]:
         raise fv.VerifyError("FRI caps differ from the committed caps")
@@ -390,7 +509,7 @@ def verify_plonk(proof_bytes, oracle, pos_consts=None, public=None):
     zeta = info["zeta"]
     pre, wires, zs, quot = (info["openings_at"][(0, b)] for b in range(4))
     zs_next = info["openings_at"][(1, 2)]
-    consts, sigmas = pre[:NCONST], pre[NCONST:]
+    consts, sigmas = pre[:n_const(flags)], pre[n_const(flags):]
     ks = ks_of(R)
     zn = zeta
     for _ in range(log_n):

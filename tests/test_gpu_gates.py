@@ -152,3 +152,77 @@ def test_k7_direct_parity_extended_gates(setup, pkg):
     L = {name: lde(vals) for name, vals in (("consts", circ["consts"]), ("sigmas", circ["sigmas"]), ("wires", circ["wires"]), ("zs", zs))}
     assert [[int(v) for v in r] for r in got] == pref.ref_quotient(circ, L, beta, gamma, alpha, rb)
     ck.free()
+
+
+@pytest.mark.parametrize("log_n,W,R,n_public,n_sha,n_pos", [(8, 144, 80, 2, 60, 10), (6, 160, 16, 0, 20, 0), (9, 144, 24, 0, 300, 0)])
+def test_sha_gate_circuit(setup, pkg, log_n, W, R, n_public, n_sha, n_pos):
+    """SHA-256 rows (E / A / W / ADD kinds at random): the GPU witness filler rebuilds every bit wire from the routed words, the circuit
+    proves and verifies with the native and the independent verifier (alone and mixed with Poseidon rows), a flipped bit wire or a
+    wrong output word yields no accepted proof, and K6 matches the restatement"""
+    prover, oracle = setup
+    consts = poseidon_consts("small")
+    rng = np.random.default_rng(log_n * 77 + n_sha)
+    n = 1 << log_n
+    special = [int(v) for v in rng.choice(np.arange(n_public, n), size=n_sha + n_pos, replace=False)]
+    sha_rows, pos_rows = sorted(special[:n_sha]), sorted(special[n_sha:])
+    circ = pref.build_circuit(rng, log_n, W, n_routed=R, n_public=n_public, poseidon_rows=pos_rows, consts=consts, sha_rows=sha_rows)
+    wires = circ["wires"]
+    assert circ["consts"].shape[0] == pref.NCONST_SHA and circ["flags"] & pref.FLAG_SHA
+    kinds = [int(np.argmax(circ["consts"][6:10, r])) for r in sha_rows]
+    assert sorted(set(kinds)) == [0, 1, 2, 3]
+    blank = wires.copy()
+    blank[12:pref.SHA_WIRES, sha_rows] = 0
+    dw = prover.to_device(blank)
+    prover.sha_gate_fill_rows(dw, log_n, W, sha_rows, kinds)
+    assert np.array_equal(dw.download(wires.shape), wires)
+    ck = pkg.PlonkCircuit(prover, circ["consts"], circ["sigmas"], n_wires=W, n_public=n_public, poseidon=bool(pos_rows), sha=True)
+    proof = ck.prove_(dw, 10, 6, public=circ["public"])
+    dw.free()
+    assert ck.verify(proof, 10, 6, public=circ["public"] if n_public else None), prover.last_reject
+    info = pref.verify_plonk(proof, oracle, pos_consts=consts if pos_rows else None, public=circ["public"])
+    assert info["flags"] == circ["flags"]
+    for wire, row in ((12 + 5, sha_rows[0]), (140, sha_rows[1]), (108 + 31, sha_rows[2]), (4, sha_rows[3]), (76, sha_rows[4])):
+        bad = wires.copy()
+        bad[wire, row] ^= np.uint64(1)
+        try:
+            p2 = ck.prove(bad, 10, 6, public=circ["public"])
+        except pkg.GlpError:
+            p2 = None
+        if p2 is not None:
+            assert not ck.verify(p2, 10, 6, public=circ["public"] if n_public else None), (wire, row)
+    beta = [int(v) for v in rand_field(rng, 2)]
+    gamma = [int(v) for v in rand_field(rng, 2)]
+    assert np.array_equal(ck.debug_stage(wires, "zs", beta + gamma, public=circ["public"]), pref.ref_zs(circ, beta, gamma))
+    ck.free()
+
+
+def test_k7_direct_parity_sha_rows(setup, pkg):
+    """row a7 directly on the GPU for a circuit with SHA rows of every kind next to Poseidon rows, arithmetic gates and public inputs:
+    the quotient values of K7 + K7s equal the big-int restatement point for point"""
+    prover, oracle = setup
+    consts = poseidon_consts("small")
+    rng = np.random.default_rng(92)
+    log_n, W, R, rb = 5, 144, 32, 3
+    for attempt in range(20):
+        circ = pref.build_circuit(rng, log_n, W, n_routed=R, n_public=3, poseidon_rows=(4, 20), consts=consts, sha_rows=(5, 6, 7, 8, 9, 21, 22, 23, 30))
+        if len({int(np.argmax(circ["consts"][6:10, r])) for r in (5, 6, 7, 8, 9, 21, 22, 23, 30)}) == 4:
+            break
+    ck = pkg.PlonkCircuit(prover, circ["consts"], circ["sigmas"], n_wires=W, n_public=3, poseidon=True, sha=True)
+    beta = [int(v) for v in rand_field(rng, 2)]
+    gamma = [int(v) for v in rand_field(rng, 2)]
+    alpha = [int(v) for v in rand_field(rng, 2)]
+    got = ck.debug_stage(circ["wires"], "quotient", beta + gamma + alpha, public=circ["public"])
+    zs = pref.ref_zs(circ, beta, gamma)
+
+    def lde(vals):
+        co = np.ascontiguousarray(vals).copy()
+        k = co.shape[0]
+        oracle.orc_ntt(ptr(co), log_n, k, 1)
+        out = np.zeros((k, 1 << (log_n + rb)), dtype=np.uint64)
+        oracle.orc_lde_coset(ptr(co), ptr(out), log_n, rb, k, 7)
+        oracle.orc_bitrev_rows(ptr(out), log_n + rb, k)
+        return [[int(x) for x in r] for r in out]
+
+    L = {name: lde(vals) for name, vals in (("consts", circ["consts"]), ("sigmas", circ["sigmas"]), ("wires", circ["wires"]), ("zs", zs))}
+    assert [[int(v) for v in r] for r in got] == pref.ref_quotient(circ, L, beta, gamma, alpha, rb)
+    ck.free()
