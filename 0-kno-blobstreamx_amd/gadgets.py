@@ -158,6 +158,91 @@ class Sha256Gadget:
         return (bits, w)
 
 
+class Sha256Rows:
+    """SHA-256 on the SHA row gates (csrc/plonk_gates.h): words are single variables holding 32-bit values; one compression
+    is 48 W + 64 E + 64 A + 2 ADD rows instead of ~66k arithmetic gates.  Inputs handed to `compress` must be range-checked words
+    (outputs of rows are; free inputs go through `word`)."""
+
+    def __init__(self, builder):
+        self.b = builder
+        self.zero = builder.constant(0)
+        self.c2_8, self.c2_24 = builder.constant(1 << 8), builder.constant(1 << 24)
+        self.one = builder.constant(1)
+
+    def word(self, v):
+        """range-check a variable as a 32-bit word"""
+        return self.b.range32(v)
+
+    def public_word(self, value):
+        w = self.b.var(value)
+        self.b.range32(w)
+        self.b.public_input(w)
+        return w
+
+    def compress(self, state, block):
+        """state: 8 words, block: 16 words -> 8 words (FIPS 180-4 section 6.2.2)"""
+        b = self.b
+        w = list(block)
+        for t in range(16, 64):
+            w.append(b.sha_w(w[t - 16], w[t - 15], w[t - 7], w[t - 2]))
+        a, bb, c, d, e, f, g, h = state
+        for t in range(64):
+            t1, e_new = b.sha_e(e, f, g, h, d, w[t], K256[t])
+            a_new = b.sha_a(a, bb, c, t1)
+            a, bb, c, d, e, f, g, h = a_new, a, bb, c, e_new, e, f, g
+        return [b.add32(x, y) for x, y in zip(state, (a, bb, c, d, e, f, g, h))]
+
+    def split_byte(self, w):
+        """a word as (top 24 bits, low byte): w = hi * 2^8 + lo with hi < 2^24 and lo < 2^8 (each bound = two 32-bit range checks:
+        v < 2^32 and v * 2^k < 2^32 as integers, since v * 2^k < 2^56 cannot wrap)"""
+        b = self.b
+        hi, lo = b.bit_field(w, 8, 24), b.bit_field(w, 0, 8)
+        b.assert_equal(b.arith(1, 1, 0, hi, self.c2_8, lo), w)
+        b.range32(hi)
+        b.range32(lo)
+        b.range32(b.arith(1, 0, 0, hi, self.c2_8, hi))
+        b.range32(b.arith(1, 0, 0, lo, self.c2_24, lo))
+        return hi, lo
+
+    def hash_prefixed_64(self, prefix, words16):
+        """SHA-256(prefix byte || the 64 bytes of 16 big-endian words): the RFC 6962 leaf (0x00) / inner-node (0x01) hashes.  The prefix shifts
+        the data by one byte: message word j = low byte of data word j-1, then the top three bytes of data word j."""
+        b = self.b
+        parts = [self.split_byte(w) for w in words16]
+        msg = [b.arith(0, 1, prefix << 24, self.zero, self.zero, parts[0][0])]                    # prefix * 2^24 + hi_0
+        for j in range(1, 16):
+            msg.append(b.arith(1, 1, 0, parts[j - 1][1], self.c2_24, parts[j][0]))               # lo_{j-1} * 2^24 + hi_j
+        msg.append(b.arith(1, 0, 0x80 << 16, parts[15][1], self.c2_24, self.zero))               # lo_15 * 2^24 + 0x80 * 2^16
+        msg += [self.zero] * 14 + [b.constant(65 * 8)]                                            # padding, 64-bit length
+        state = [b.constant(v) for v in IV256]
+        for off in (0, 16):
+            state = self.compress(state, msg[off:off + 16])
+        return state
+
+
+def data_commitment_rows_circuit(prover, heights, data_roots):
+    """DataCommitment over a power-of-two block range on the SHA row gates: the same statement as data_commitment_circuit (public inputs:
+    per block the 16 big-endian words of abi.encode(height, dataRoot), then the 8 words of the commitment root) in ~370 rows per hash
+    instead of ~6.6k.  Returns (circuit, device wires, public values, root bytes)."""
+    from . import SHA_GATE_WIRES
+    n = len(heights)
+    assert n >= 1 and n & (n - 1) == 0 and len(data_roots) == n
+    b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
+    g = Sha256Rows(b)
+    level = []
+    for hgt, root in zip(heights, data_roots):
+        tup = int(hgt).to_bytes(32, "big") + bytes(root)
+        words = [g.public_word(struct.unpack(">I", tup[4 * k: 4 * k + 4])[0]) for k in range(16)]
+        level.append(g.hash_prefixed_64(0x00, words))
+    while len(level) > 1:
+        level = [g.hash_prefixed_64(0x01, level[k] + level[k + 1]) for k in range(0, len(level), 2)]
+    for w in level[0]:
+        b.public_input(w)
+    root = b"".join(struct.pack(">I", b.value(w)) for w in level[0])
+    ck, dw, public = b.build()
+    return ck, dw, public, root
+
+
 def data_commitment_circuit(prover, heights, data_roots):
     """DataCommitment over a power-of-two block range, constrained in-circuit.  Returns (circuit, device wires, public values,
     root bytes).  Public values: per block 16 big-endian words of abi.encode(height, dataRoot) (32-byte big-endian height, 32-byte

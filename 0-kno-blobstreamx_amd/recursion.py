@@ -15,7 +15,8 @@ needs extension-field arithmetic gadgets and the transcript in-circuit, listed i
 """
 import numpy as np
 
-from . import CIRCUIT_POSEIDON_GATE, P, PLONK_NCONST, POS_GATE_WIRES, DeviceBuffer, PlonkCircuit  # noqa: F401
+from . import (CIRCUIT_POSEIDON_GATE, P, PLONK_NCONST, PLONK_NCONST_SHA, POS_GATE_WIRES, SHA_GATE_WIRES, SHA_ROW_A, SHA_ROW_ADD, SHA_ROW_E,  # noqa: F401
+               SHA_ROW_W, DeviceBuffer, PlonkCircuit)
 
 
 class CircuitBuilder:
@@ -29,6 +30,8 @@ class CircuitBuilder:
         self.parent = []                 # union-find over variables (copy constraints)
         self.arith_rows = {}             # (c0, c1, c2) -> list of rows, a row = list of (x, y, z, w) variable tuples
         self.pos_rows = []               # (in vars[12], out vars[12])
+        self.sha_rows = []               # (kind, [12 variables or None], K): SHA-256 rows (csrc/plonk_gates.h); needs n_wires >= 144
+        self._add_open = None            # the ADD row still taking additions (4 per row)
         self.public = []
         self._consts = {}
         # the straight-line program that recomputes every variable from the free inputs (WitnessProgram / glp_witness_eval)
@@ -155,6 +158,67 @@ class CircuitBuilder:
         self.pos_rows.append((list(ins), outs))
         return outs
 
+    # ---- SHA-256 rows: words (32-bit values) in, words out; the row's bit wires are filled on the device ------------------------------
+    _M32 = 0xFFFFFFFF
+
+    def _word(self, v):
+        val = self.values[v]
+        if val >> 32:
+            raise ValueError("a SHA row input is not a 32-bit word: the witness does not satisfy the circuit")
+        return val
+
+    def sha_e(self, e, f, g, h, d, w, k_const):
+        """e-half of round t: returns (T1, e_new) with T1 = h + Sigma1(e) + Ch(e,f,g) + K_t + w (unreduced) and e_new = (d + T1) mod 2^32.
+        The row range-checks e, f, g and e_new; h, d, w must be range-checked words where they come from."""
+        assert self.W >= SHA_GATE_WIRES
+        ev, fv, gv, hv, dv, wv = (self._word(x) for x in (e, f, g, h, d, w))
+        rot = lambda x, r: ((x >> r) | (x << (32 - r))) & self._M32
+        t1v = hv + (rot(ev, 6) ^ rot(ev, 11) ^ rot(ev, 25)) + ((ev & fv) ^ (~ev & gv & self._M32)) + int(k_const) + wv
+        t1, en = self._new(t1v), self._new((dv + t1v) & self._M32)
+        self.prog += (7, t1, en, e, f, g, h, d, w, int(k_const))
+        self.sha_rows.append((SHA_ROW_E, [e, f, g, h, d, w, t1, en], int(k_const)))
+        return t1, en
+
+    def sha_a(self, a, b, c, t1):
+        """a-half of the round: a_new = (T1 + Sigma0(a) + Maj(a,b,c)) mod 2^32 (range-checks a, b, c, a_new; T1 comes from sha_e)"""
+        av, bv, cv = (self._word(x) for x in (a, b, c))
+        rot = lambda x, r: ((x >> r) | (x << (32 - r))) & self._M32
+        an = self._new((self.values[t1] + (rot(av, 2) ^ rot(av, 13) ^ rot(av, 22)) + ((av & bv) ^ (av & cv) ^ (bv & cv))) & self._M32)
+        self.prog += (8, an, a, b, c, t1)
+        self.sha_rows.append((SHA_ROW_A, [a, b, c, t1, an], 0))
+        return an
+
+    def sha_w(self, w16, w15, w7, w2):
+        """message schedule: (w16 + sigma0(w15) + w7 + sigma1(w2)) mod 2^32 (range-checks w15, w2 and the result)"""
+        v16, v15, v7, v2 = (self._word(x) for x in (w16, w15, w7, w2))
+        rot = lambda x, r: ((x >> r) | (x << (32 - r))) & self._M32
+        wn = self._new((v16 + (rot(v15, 7) ^ rot(v15, 18) ^ (v15 >> 3)) + v7 + (rot(v2, 17) ^ rot(v2, 19) ^ (v2 >> 10))) & self._M32)
+        self.prog += (9, wn, w16, w15, w7, w2)
+        self.sha_rows.append((SHA_ROW_W, [w16, w15, w7, w2, wn], 0))
+        return wn
+
+    def add32(self, x, y):
+        """(x + y) mod 2^32 for words x, y; the result is range-checked (four additions share one ADD row)"""
+        assert self.W >= SHA_GATE_WIRES
+        s = self._new((self._word(x) + self._word(y)) & self._M32)
+        self.prog += (10, s, x, y)
+        if self._add_open is None or len(self._add_open) == 12:
+            self._add_open = []
+            self.sha_rows.append((SHA_ROW_ADD, self._add_open, 0))
+        self._add_open += [x, y, s]
+        return s
+
+    def range32(self, x):
+        """x < 2^32: x + 0 through an ADD row, whose result (bits and all) is copy-constrained back to x"""
+        self.assert_equal(self.add32(x, self.constant(0)), x)
+        return x
+
+    def bit_field(self, x, shift, bits):
+        """(x >> shift) mod 2^bits of the canonical value (a computed witness: the caller constrains it)"""
+        v = self._new((self.values[x] >> shift) & ((1 << bits) - 1))
+        self.prog += (11, v, x, shift, bits)
+        return v
+
     def two_to_one(self, left4, right4):
         """PoseidonHash::two_to_one: permute(left || right || 0 0 0 0)[0..4)"""
         zero = self.constant(0)
@@ -205,10 +269,10 @@ class WitnessProgram:
         W, R, G = b.W, b.R, b.G
         self.W, self.R = W, R
         arith = [(key, row) for key, rows in sorted(b.arith_rows.items()) for row in rows if row]
-        n_rows = len(b.public) + len(b.pos_rows) + len(arith)
+        n_rows = len(b.public) + len(b.pos_rows) + len(b.sha_rows) + len(arith)
         self.log_n = max(3, (max(n_rows, 1) - 1).bit_length())
         n = 1 << self.log_n
-        consts = np.zeros((PLONK_NCONST, n), dtype=np.uint64)
+        consts = np.zeros((PLONK_NCONST_SHA if b.sha_rows else PLONK_NCONST, n), dtype=np.uint64)
         fixed = []                                   # (wire, row, value): cells of unused gate slots that must hold c2
         cj, ci, cv = [], [], []                      # placed cells: wire, row, variable
         i = 0
@@ -225,6 +289,15 @@ class WitnessProgram:
                 cj.append(12 + j); ci.append(i); cv.append(v)
             self.pos_row_ids.append(i)
             i += 1
+        sha_ids, sha_kinds = [], []
+        for kind, words, k_const in b.sha_rows:
+            consts[6 + kind, i], consts[3, i] = 1, k_const
+            for j, v in enumerate(words):
+                cj.append(j); ci.append(i); cv.append(v)
+            sha_ids.append(i)
+            sha_kinds.append(kind)
+            i += 1
+        self.sha_row_ids, self.sha_kinds = np.array(sha_ids, dtype=np.uint32), np.array(sha_kinds, dtype=np.uint32)
         for (c0, c1, c2), row in arith:
             consts[0, i], consts[1, i], consts[2, i], consts[3, i] = 1, c0, c1, c2
             for g, slot in enumerate(row):
@@ -261,10 +334,12 @@ class WitnessProgram:
         self.wc_bits = np.array([(c[1][0], c[1][1], len(c[2])) for c in bits], dtype=np.int64).reshape(-1, 3)
         self.wc_bit_vars = np.array([v for c in bits for v in c[2]], dtype=np.int64)
         self.stats = {"rows": n, "poseidon_rows": len(b.pos_rows), "arith_gates": sum(len(r) for _, r in arith), "variables": self.n_values,
-                      "inputs": self.n_inputs}
+                      "inputs": self.n_inputs, "sha_rows": len(b.sha_rows), "rows_used": n_rows}
         self._finish()
 
-    _SAVED = ("consts", "cj", "ci", "cv", "fixed", "pos_row_ids", "public_vars", "roots", "prog", "eq_pairs", "wc_const", "wc_var", "wc_bits", "wc_bit_vars")
+    _SAVED = ("consts", "cj", "ci", "cv", "fixed", "pos_row_ids", "sha_row_ids", "sha_kinds", "public_vars", "roots", "prog", "eq_pairs", "wc_const", "wc_var",
+              "wc_bits", "wc_bit_vars")
+    _STATS = ("rows", "poseidon_rows", "arith_gates", "variables", "inputs", "sha_rows", "rows_used")
 
     def _finish(self):
         """what is derived from the recorded arrays: the cell -> variable map of the whole wire matrix (0xFFFFFFFF = zero; an unused gate slot
@@ -285,7 +360,7 @@ class WitnessProgram:
         arrays = {k: getattr(self, k) for k in self._SAVED}
         arrays["input_tags"] = self.input_tags if self.input_tags is not None else np.zeros((0, 2), dtype=np.int64)
         arrays["seg_bounds"] = self.seg_bounds if self.seg_bounds is not None else np.zeros(0, dtype=np.uint64)
-        arrays["stats"] = np.array([self.stats[k] for k in ("rows", "poseidon_rows", "arith_gates", "variables", "inputs")], dtype=np.int64)
+        arrays["stats"] = np.array([self.stats[k] for k in self._STATS], dtype=np.int64)
         np.savez(path, meta=meta, **arrays)
 
     @classmethod
@@ -297,9 +372,9 @@ class WitnessProgram:
                 setattr(self, k, z[k])
             self.input_tags = None if tagged < 0 else z["input_tags"]
             self.seg_bounds = z["seg_bounds"] if z["seg_bounds"].size else None
-            self.stats = dict(zip(("rows", "poseidon_rows", "arith_gates", "variables", "inputs"), (int(v) for v in z["stats"])))
+            self.stats = dict(zip(cls._STATS, (int(v) for v in z["stats"])))
         n = 1 << self.log_n
-        if (self.consts.shape != (PLONK_NCONST, n) or self.roots.size != self.n_values or not (self.cj.size == self.ci.size == self.cv.size)
+        if (self.consts.shape not in ((PLONK_NCONST, n), (PLONK_NCONST_SHA, n)) or self.sha_row_ids.size != self.sha_kinds.size or self.roots.size != self.n_values or not (self.cj.size == self.ci.size == self.cv.size)
                 or (self.cv.size and (self.cv.max() >= self.n_values or self.cj.max() >= self.R or self.ci.max() >= n))):
             raise ValueError("not a recorded circuit of this format")
         self._finish()
@@ -327,7 +402,8 @@ class WitnessProgram:
         delta[1] = 1
         wp = prover.fft(delta)                                                         # w_n^r, r < n
         sigma = prover.field_op("mul", ks[tgt_col], wp[tgt_row])
-        return PlonkCircuit(prover, self.consts, sigma, cap_height=cap_height, n_wires=self.W, n_public=len(self.public_vars), poseidon=True)
+        return PlonkCircuit(prover, self.consts, sigma, cap_height=cap_height, n_wires=self.W, n_public=len(self.public_vars), poseidon=True,
+                            sha=self.consts.shape[0] == PLONK_NCONST_SHA)
 
     def evaluate(self, poseidon_consts, inputs, threads=None):
         """every variable's value for new inputs (glp_witness_eval_mt: the recorded segments on `threads` host threads, default all cores);
@@ -349,7 +425,8 @@ class WitnessProgram:
                                         self.eq_pairs.ctypes.data if self.eq_pairs.size else None, self.eq_pairs.size // 2, ctypes.byref(bad),
                                         sb.ctypes.data if sb is not None else None, sb.size - 1 if sb is not None else 0, nt)
         if rcode == -7:
-            raise ValueError(f"the inputs do not satisfy the circuit (copy constraint {bad.value} fails)")
+            what = "a SHA row input is not a 32-bit word" if bad.value == ctypes.c_size_t(-1).value else f"copy constraint {bad.value} fails"
+            raise ValueError(f"the inputs do not satisfy the circuit ({what})")
         if rcode != 0:
             raise ValueError("witness program or inputs malformed")
         return vals
@@ -402,6 +479,7 @@ class WitnessProgram:
         finally:
             src.free()
         prover.poseidon_gate_fill_rows(dw, self.log_n, self.W, self.pos_row_ids)
+        prover.sha_gate_fill_rows(dw, self.log_n, self.W, self.sha_row_ids, self.sha_kinds)
         return dw, [int(v) for v in vals[self.public_vars]]
 
     def release(self, prover=None):
