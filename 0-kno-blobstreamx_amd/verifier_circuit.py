@@ -222,11 +222,68 @@ def _poseidon_row_constraints(g, wires, consts):
     return out
 
 
+def _sha_row_constraints(g, wires, q4, c2):
+    """the 140 selector-weighted constraint values of the SHA-row block (csrc/plonk_gates.h) on extension-field wire values"""
+    qE, qA, qW, qD = q4
+    q_any = g.e_add(g.e_add(qE, qA), g.e_add(qW, qD))
+    two, zero_e = g.k(2), g.e_from_base(g.zero)
+    out = [g.e_mul(q_any, g.e_sub(g.e_mul(v, v), v)) for v in wires[12:144]]
+    X, Y, Z, N, cw = wires[12:44], wires[44:76], wires[76:108], wires[108:140], wires[140:144]
+
+    def pack(bits):
+        acc = bits[-1]
+        for v in reversed(bits[:-1]):                                      # Horner from the top bit: 2 * acc + bit
+            acc = (g.b.arith(1, 1, 0, acc[0], two, v[0]), g.b.arith(1, 1, 0, acc[1], two, v[1]))
+        return acc
+
+    def xor(x, y):                                                         # x + y - 2xy
+        m = g.e_mul(x, y)
+        return g.e_sub(g.e_add(x, y), g.e_scale_const(m, 2))
+
+    px, py, pz, pn = pack(X), pack(Y), pack(Z), pack(N)
+    ch = pack([g.e_add(z, g.e_mul(x, g.e_sub(y, z))) for x, y, z in zip(X, Y, Z)])
+    maj = pack([g.e_add(g.e_mul(x, y), g.e_mul(z, xor(x, y))) for x, y, z in zip(X, Y, Z)])
+    S1 = pack([xor(xor(X[(i + 6) % 32], X[(i + 11) % 32]), X[(i + 25) % 32]) for i in range(32)])
+    S0 = pack([xor(xor(X[(i + 2) % 32], X[(i + 13) % 32]), X[(i + 22) % 32]) for i in range(32)])
+    s0 = pack([xor(xor(X[(i + 7) % 32], X[(i + 18) % 32]), X[i + 3]) if i + 3 < 32 else xor(X[(i + 7) % 32], X[(i + 18) % 32]) for i in range(32)])
+    s1 = pack([xor(xor(Y[(i + 17) % 32], Y[(i + 19) % 32]), Y[i + 10]) if i + 10 < 32 else xor(Y[(i + 17) % 32], Y[(i + 19) % 32]) for i in range(32)])
+    w = wires
+    two32 = 1 << 32
+    car2 = g.e_add(cw[0], g.e_scale_const(cw[1], 2))
+    car3 = g.e_add(car2, g.e_scale_const(cw[2], 4))
+
+    def mix(e, a, ww, d):
+        acc = None
+        for q, v in ((qE, e), (qA, a), (qW, ww), (qD, d)):
+            if v is not None:
+                t = g.e_mul(q, v)
+                acc = t if acc is None else g.e_add(acc, t)
+        return acc
+
+    out.append(mix(g.e_sub(px, w[0]), g.e_sub(px, w[0]), g.e_sub(px, w[1]), g.e_sub(px, w[2])))
+    out.append(mix(g.e_sub(py, w[1]), g.e_sub(py, w[1]), g.e_sub(py, w[3]), g.e_sub(py, w[5])))
+    out.append(mix(g.e_sub(pz, w[2]), g.e_sub(pz, w[2]), None, g.e_sub(pz, w[8])))
+    out.append(mix(g.e_sub(pn, w[7]), g.e_sub(pn, w[4]), g.e_sub(pn, w[4]), g.e_sub(pn, w[11])))
+    e4 = g.e_sub(w[6], g.e_add(g.e_add(g.e_add(w[3], S1), g.e_add(ch, c2)), w[5]))
+    a4 = g.e_sub(g.e_add(w[4], g.e_scale_const(car3, two32)), g.e_add(g.e_add(w[3], S0), maj))
+    w4 = g.e_sub(g.e_add(w[4], g.e_scale_const(car2, two32)), g.e_add(g.e_add(w[0], s0), g.e_add(w[2], s1)))
+    d4 = g.e_sub(g.e_add(w[2], g.e_scale_const(cw[0], two32)), g.e_add(w[0], w[1]))
+    out.append(mix(e4, a4, w4, d4))
+    e5 = g.e_sub(g.e_add(w[7], g.e_scale_const(car3, two32)), g.e_add(w[4], w[6]))
+    d5 = g.e_sub(g.e_add(w[5], g.e_scale_const(cw[1], two32)), g.e_add(w[3], w[4]))
+    out.append(mix(e5, None, None, d5))
+    out.append(g.e_mul(qD, g.e_sub(g.e_add(w[8], g.e_scale_const(cw[2], two32)), g.e_add(w[6], w[7]))))
+    out.append(g.e_mul(qD, g.e_sub(g.e_add(w[11], g.e_scale_const(cw[3], two32)), g.e_add(w[9], w[10]))))
+    assert len(out) == 140 and zero_e is not None
+    return out
+
+
 def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4, poseidon_consts=None,
-                      proof_id=0):
+                      proof_id=0, sha=False):
     """lay the whole verification of `proof` down on builder `b` (see the module docstring).  The expected statement shape and the leaf
     circuit's key are CONSTANTS of the resulting circuit.  poseidon_consts = (rc, circ, diag): the child is a Poseidon-row circuit (flags = 1,
     e.g. a proof made by this very function's circuit: recursion on recursion); its 118 row constraints are then part of the identity.
+    sha: the child has SHA-256 rows (flag 2, ten constant columns): the 140 constraints of that block join the identity too.
     Returns {"public": [vars], "digest": [4 vars]}."""
     import numpy as np
     g = _G(b)
@@ -261,7 +318,8 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     # ---- statement: header (constants), public inputs, the circuit's key (constants), then the prover's caps ----------------------
     log_n = words[1] if len(words) > 1 else 0
     rb = 3
-    flags = 1 if poseidon_consts is not None else 0
+    flags = (1 if poseidon_consts is not None else 0) | (2 if sha else 0)
+    nconst = 10 if sha else NCONST
     if poseidon_consts is not None:
         poseidon_consts = tuple([int(v) for v in a] for a in poseidon_consts)
     if not 3 <= log_n <= 24:
@@ -298,7 +356,7 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     # ---- FRI part: parameters are constants of this circuit ---------------------------------------------------------------------
     a_bits, fb = 4, min(5, log_n)
     gen = _root(log_n)
-    n_polys = [NCONST + R, n_wires, NCHAL * M, NCHAL << rb]
+    n_polys = [nconst + R, n_wires, NCHAL * M, NCHAL << rb]
     masks = [1, 1, 3, 1]
     fhdr = [FRI_TAG, log_n, rb, cap0, a_bits, fb, num_queries, pow_bits, 7, 4, 2, 1, gen]
     for npk, mk in zip(n_polys, masks):
@@ -462,7 +520,7 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     zs = openings[offs[(0, 2)]: offs[(0, 2)] + n_polys[2]]
     quot = openings[offs[(0, 3)]: offs[(0, 3)] + n_polys[3]]
     zs_next = openings[offs[(1, 2)]: offs[(1, 2)] + n_polys[2]]
-    consts, sigmas = pre[:NCONST], pre[NCONST:]
+    consts, sigmas = pre[:nconst], pre[nconst:]
     ks = [pow(7, j, P) for j in range(R)]
     one_e = g.e_from_base(g.one)
     zn = zeta
@@ -478,8 +536,9 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
         pi_z = g.e_add(pi_z, g.e_scale(li, pv))
         wi = wi * gen % P
     l1 = g.e_mul(zh, g.e_inv(g.e_scale_const(g.e_sub(zeta, one_e), n % P)))
-    q_ar, c0, c1, c2, q_pi, q_pos = consts
-    pos_cons = _poseidon_row_constraints(g, wires, poseidon_consts) if flags else []
+    q_ar, c0, c1, c2, q_pi, q_pos = consts[:6]
+    pos_cons = _poseidon_row_constraints(g, wires, poseidon_consts) if flags & 1 else []
+    sha_cons = _sha_row_constraints(g, wires, consts[6:10], c2) if sha else []
     for t in range(NCHAL):
         acc = g.e_mul(l1, g.e_sub(zs[t * M], one_e))
         ap = alpha[t]
@@ -502,12 +561,15 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
                 ap = g.mul(ap, alpha[t])
                 acc = g.e_add(acc, g.e_scale(con, ap))
             prev = nxt
-        if flags:
+        if flags & 1:
             pacc = g.e_from_base(g.zero)
             for con in pos_cons:
                 ap = g.mul(ap, alpha[t])
                 pacc = g.e_add(pacc, g.e_scale(con, ap))
             acc = g.e_add(acc, g.e_mul(q_pos, pacc))
+        for con in sha_cons:
+            ap = g.mul(ap, alpha[t])
+            acc = g.e_add(acc, g.e_scale(con, ap))
         tz, zp = g.e_from_base(g.zero), one_e
         for c in range(1 << rb):
             tz = g.e_add(tz, g.e_mul(zp, quot[t * (1 << rb) + c]))
@@ -517,7 +579,7 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
 
 
 def recursive_aggregation_circuit(prover, proofs, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4,
-                                  poseidon_consts=None):
+                                  poseidon_consts=None, sha=False):
     """ONE circuit that verifies every proof in `proofs` (all of the same leaf circuit `leaf_key`, same parameters) and folds their digests into a
     Poseidon Merkle root: the Reduce step as a real recursion, fan-in len(proofs).  Public inputs: each leaf's public inputs, each leaf's
     4-word digest (leaf order), then the 4-word root.  A verifier of the resulting proof needs no leaf proof: the leaf circuit's key and the
@@ -528,7 +590,8 @@ def recursive_aggregation_circuit(prover, proofs, leaf_key, num_queries, pow_bit
     b = CircuitBuilder(prover)
     level = []
     for k, proof in enumerate(proofs):
-        out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height, poseidon_consts, proof_id=k)
+        out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height, poseidon_consts, proof_id=k,
+                                sha=sha)
         for v in out["public"] + out["digest"]:
             b.public_input(v)
         level.append(out["digest"])
@@ -549,7 +612,7 @@ class RecursionProgram:
     (ValueError): some copy constraint of the verifier circuit fails on its witness."""
 
     def __init__(self, prover, sample_proofs, leaf_key, num_queries, pow_bits, n_wires, poseidon_values, n_routed=None, n_public=0, cap_height=4,
-                 child_is_recursion=False):
+                 child_is_recursion=False, child_sha=False):
         from .recursion import CircuitBuilder
         n = len(sample_proofs)
         assert n >= 1 and n & (n - 1) == 0, "a power-of-two number of proofs"
@@ -559,7 +622,7 @@ class RecursionProgram:
         for k, proof in enumerate(sample_proofs):
             b.begin_segment()            # one proof's verifier depends on constants and on itself: the witness evaluator runs them in parallel
             out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height,
-                                    poseidon_values if child_is_recursion else None, proof_id=k)
+                                    poseidon_values if child_is_recursion else None, proof_id=k, sha=child_sha)
             b.end_segment()
             for v in out["public"] + out["digest"]:
                 b.public_input(v)

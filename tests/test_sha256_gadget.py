@@ -164,3 +164,44 @@ def test_data_commitment_on_sha_rows(prover, oracle, pkg):
     assert bad is None or not ck.verify(bad, 28, 16, public=public)
     dw.free()
     ck.free()
+
+
+@pytest.mark.gpu
+def test_recursion_over_data_commitment_proofs(prover, oracle, pkg):
+    """two DataCommitment proofs (SHA rows + Poseidon flag: header flags 3, ten constant columns) verified completely IN-CIRCUIT — the 140
+    SHA-row constraints at zeta included — by one recursion proof whose public inputs are the leaves' statements, digests and the root"""
+    gd, rec, bs = _mods()
+    vc = importlib.import_module(graft.PKG_NAME + ".verifier_circuit")
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    rng = np.random.default_rng(4098)
+    nq, pw = 6, 4
+    leaves, key, shape = [], None, None
+    for k in range(2):
+        heights = [5000 + 2 * k, 5001 + 2 * k]
+        roots = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in heights]
+        ck, dw, public, root = gd.data_commitment_rows_circuit(prover, heights, roots)
+        proof = ck.prove_(dw, nq, pw, public=public)
+        assert ck.verify(proof, nq, pw, public=public)
+        if key is None:
+            key, shape = ck.cap(), (ck.n_wires, ck.n_routed, len(public))
+        assert np.array_equal(key, ck.cap()), "every range of the same size shares one circuit"
+        leaves.append((proof, public, root))
+        dw.free()
+        ck.free()
+    W, R, n_pub = shape
+    rp = vc.RecursionProgram(prover, [p for p, _, _ in leaves], key, nq, pw, W, consts, n_routed=R, n_public=n_pub, cap_height=1, child_is_recursion=True,
+                             child_sha=True)
+    proof, public = rp.prove([p for p, _, _ in leaves], 8, 4)
+    digests = [prover.proof_digest(p) for p, _, _ in leaves]
+    want = [v for (_, pub, _), d in zip(leaves, digests) for v in pub + d] + rec.merkle_root_host(prover, digests)
+    assert public == want
+    assert prover.plonk_verify(proof, rp.key(), 8, 4, public=public), prover.last_reject
+    pref.verify_plonk(proof, oracle, pos_consts=consts, public=public)
+    # a DataCommitment proof with one flipped word is refused by the recorded program
+    bad = np.frombuffer(leaves[1][0], dtype="<u8").copy()
+    bad[len(bad) // 2] ^= np.uint64(1)
+    with pytest.raises(ValueError):
+        rp.prove([leaves[0][0], bad.tobytes()], 8, 4)
+    rp.free()
