@@ -37,7 +37,7 @@ def _oracle_prover(oracle):
     return OracleProver()
 
 
-@pytest.mark.parametrize("which", ["plonk", "gates"])
+@pytest.mark.parametrize("which", ["plonk", "gates", "sha"])
 def test_c_evaluator_reproduces_the_builders_witness(oracle, which):
     rec, vc, _, _ = _mods()
     consts = poseidon_consts("small")
@@ -46,7 +46,7 @@ def test_c_evaluator_reproduces_the_builders_witness(oracle, which):
         g = json.load(f)[which]
     proof = bytes.fromhex(g["proof"])
     b = rec.CircuitBuilder(_oracle_prover(oracle))
-    kw = dict(n_routed=g.get("R"), n_public=g.get("n_public", 0), poseidon_consts=consts if which == "gates" else None)
+    kw = dict(n_routed=g.get("R"), n_public=g.get("n_public", 0), poseidon_consts=consts if which != "plonk" else None, sha=which == "sha")
     vc.verify_in_circuit(b, proof, g["circuit_cap"], g["queries"], g["pow_bits"], g["W"], **kw)
     prog = b.program()
     inputs, ws = prog.inputs_from_words([proof])
