@@ -127,6 +127,7 @@ def emu():
     lib.emu_plonk_quotient.argtypes = [u64p, u64p, u64p, u64p, u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                        ctypes.c_uint32, u64p, u64p, u64p, u64p, u64p]
     lib.emu_poseidon_gate_fill_rows.argtypes = [u64p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, u64p]
+    lib.emu_sha_gate_fill_rows.argtypes = [u64p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
     lib.emu_bitrev_scale.argtypes = [u64p, u64p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]
     lib.emu_ed25519_witness.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
                                         ctypes.c_void_p, ctypes.c_void_p]

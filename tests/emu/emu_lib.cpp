@@ -307,7 +307,8 @@ extern "C" int emu_plonk_zs(const u64* wires, const u64* sigmas, u32 log_n, u32 
 extern "C" int emu_plonk_quotient(const u64* consts, const u64* sigmas, const u64* wires, const u64* zs, const u64* pi, u32 log_n, u32 rb, u32 W,
                                   u32 R, u32 flags, const u64* pos_consts, const u64* beta, const u64* gamma, const u64* alpha, u64* out) {
     const u32 log_N = log_n + rb, M = R / GLP_PLONK_CHUNK;
-    const u32 n_con = 2 + 3 * M + ((flags & GLP_CIRCUIT_POSEIDON_GATE) ? GLP_POS_GATE_CONSTRAINTS : 0);
+    const u32 n_con = 2 + 3 * M + ((flags & GLP_CIRCUIT_POSEIDON_GATE) ? GLP_POS_GATE_CONSTRAINTS : 0) +
+                      ((flags & GLP_CIRCUIT_SHA_GATES) ? GLP_SHA_GATE_CONSTRAINTS : 0);
     const u64 n = 1ull << log_n, N = 1ull << log_N;
     std::vector<u64> lo(glp_table_lo_len(log_N)), hi(glp_table_hi_len(log_N) ? glp_table_hi_len(log_N) : 1), ks(R), inv(N);
     glp_fill_table(log_N, 0, lo.data(), hi.data());
@@ -326,6 +327,14 @@ extern "C" int emu_plonk_quotient(const u64* consts, const u64* sigmas, const u6
     qa.n_inv = gl_inv(n % GL_P); qa.inv_xm1 = inv.data(); qa.out = out;
     if (flags & GLP_CIRCUIT_POSEIDON_GATE) glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<true>(qa); });
     else glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<false>(qa); });
+    if (flags & GLP_CIRCUIT_SHA_GATES)      // consts then has GLP_PLONK_NCONST_SHA rows
+        glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_sha_kernel<0>(qa, n_con - GLP_SHA_GATE_CONSTRAINTS); });
+    return 0;
+}
+
+// SHA-row witness through the product's kernel: the bit wires of the listed rows from their routed words
+extern "C" int emu_sha_gate_fill_rows(u64* wires, u32 log_n, const u32* rows, const u32* kinds, u32 n_rows) {
+    glp_emu_launch((n_rows + 63) / 64, 64, 0, [&] { glp_sha_gate_fill_kernel<0>(wires, 1ull << log_n, rows, kinds, n_rows); });
     return 0;
 }
 

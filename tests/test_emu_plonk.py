@@ -58,7 +58,7 @@ def _emu_quotient(emu, oracle, circ, beta, gamma, alpha, rb=3):
         pv = np.zeros((1, n), dtype=np.uint64)
         pv[0, :circ["n_public"]] = circ["public"]
         pi, _ = lde_bitrev(oracle, pv, log_n, rb)
-    pos = np.concatenate([np.array(a, dtype=np.uint64) for a in circ["pos_consts"]]) if circ["flags"] else None
+    pos = np.concatenate([np.array(a, dtype=np.uint64) for a in circ["pos_consts"]]) if circ["flags"] & pr.FLAG_POSEIDON else None
     got = np.zeros((2, N), dtype=np.uint64)
     arr = lambda v: np.array(v, dtype=np.uint64)
     assert emu.emu_plonk_quotient(ptr(L["consts"]), ptr(L["sigmas"]), ptr(L["wires"]), ptr(L["zs"]), ptr(pi) if pi is not None else None, log_n, rb,
@@ -170,3 +170,32 @@ def test_quotient_with_public_inputs_advice_wires_and_poseidon_rows(emu, oracle,
         def corrupt(c):
             c["wires"][100, pos_rows[0]] ^= np.uint64(1)            # an advice wire of a Poseidon row (no copy constraint)
         broken(corrupt)
+
+
+@pytest.mark.parametrize("log_n,W,R,n_public,pos_rows,sha_rows", [(3, 144, 16, 1, (), (2, 3, 4, 5, 6, 7)), (4, 144, 24, 0, (1,), (0, 2, 3, 5, 8, 9, 13, 14, 15))])
+def test_quotient_with_sha_rows(emu, oracle, log_n, W, R, n_public, pos_rows, sha_rows):
+    """SHA-256 rows under emulation (ASan build included): the filler kernel rebuilds the bit wires, K7 + K7s equal the Python restatement
+    point for point, the quotient is a polynomial of degree < 8n, and a flipped bit wire or output word makes it a non-polynomial"""
+    consts = poseidon_consts("small")
+    rng = np.random.default_rng(31 * log_n + len(sha_rows))
+    circ = pr.build_circuit(rng, log_n, W, n_routed=R, n_public=n_public, poseidon_rows=pos_rows, consts=consts, sha_rows=sha_rows)
+    rows = np.array(sorted(sha_rows), dtype=np.uint32)
+    kinds = np.array([int(np.argmax(circ["consts"][6:10, r])) for r in rows], dtype=np.uint32)
+    blank = circ["wires"].copy()
+    blank[12:pr.SHA_WIRES, rows] = 0
+    assert emu.emu_sha_gate_fill_rows(ptr(blank), log_n, rows.ctypes.data, kinds.ctypes.data, len(rows)) == 0
+    assert np.array_equal(blank, circ["wires"])
+    beta = [int(v) for v in rand_field(rng, 2)]
+    gamma = [int(v) for v in rand_field(rng, 2)]
+    alpha = [int(v) for v in rand_field(rng, 2)]
+    got, want = _emu_quotient(emu, oracle, circ, beta, gamma, alpha)
+    assert [[int(v) for v in r] for r in got] == want
+    _assert_polynomial_quotient(emu, oracle, got, log_n)
+    for wire, k in ((12 + 3, 0), (108 + 30, 1), (140, 2)):
+        c2 = dict(circ)
+        c2["wires"] = circ["wires"].copy()
+        c2["wires"][wire, rows[k]] ^= np.uint64(1)
+        g2, w2 = _emu_quotient(emu, oracle, c2, beta, gamma, alpha)
+        assert [[int(v) for v in r] for r in g2] == w2
+        with pytest.raises(AssertionError):
+            _assert_polynomial_quotient(emu, oracle, g2, log_n)
