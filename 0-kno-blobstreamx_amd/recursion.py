@@ -402,8 +402,9 @@ class WitnessProgram:
         delta[1] = 1
         wp = prover.fft(delta)                                                         # w_n^r, r < n
         sigma = prover.field_op("mul", ks[tgt_col], wp[tgt_row])
-        return PlonkCircuit(prover, self.consts, sigma, cap_height=cap_height, n_wires=self.W, n_public=len(self.public_vars), poseidon=True,
-                            sha=self.consts.shape[0] == PLONK_NCONST_SHA)
+        # the flags follow the rows the circuit has: a selector column that is zero everywhere would still cost its constraints at every LDE point
+        return PlonkCircuit(prover, self.consts, sigma, cap_height=cap_height, n_wires=self.W, n_public=len(self.public_vars),
+                            poseidon=bool(self.pos_row_ids.size), sha=self.consts.shape[0] == PLONK_NCONST_SHA)
 
     def evaluate(self, poseidon_consts, inputs, threads=None):
         """every variable's value for new inputs (glp_witness_eval_mt: the recorded segments on `threads` host threads, default all cores);

@@ -489,8 +489,8 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
             dwo.free()
             cko.free()
             # ... and the Reduce as a real RECURSION: one circuit that verifies leaf proofs completely in-circuit (verifier_circuit.py) and
-            # hashes their digests into a root.  Fan-in GLP_BENCH_RECURSION_LEAVES (default 4: circuit construction is host Python, ~1 s per leaf)
-            fan = int(os.environ.get("GLP_BENCH_RECURSION_LEAVES", "4"))
+            # hashes their digests into a root.  Fan-in GLP_BENCH_RECURSION_LEAVES (default 16: recording the circuit is host Python, ~0.4 s per leaf, once)
+            fan = int(os.environ.get("GLP_BENCH_RECURSION_LEAVES", "16"))
             fan = max(1, min(1 << (fan.bit_length() - 1), len(proofs)))
             t8 = time.perf_counter()
             vcm = importlib.import_module(graft.PKG_NAME + ".verifier_circuit")
@@ -546,11 +546,12 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
     return res
 
 
-def data_commitment_leg(pkg, n_blocks=4):
-    """a circuit whose statement MEANS something: DataCommitment over n_blocks (height, dataRoot) tuples with every SHA-256 compression of
-    the RFC 6962 tree constrained in-circuit (gadgets.py; ~65.5k arithmetic gates per compression, 20 per row), public inputs = tuples + root.
-    Reports circuit construction (host Python: gate layout + witness values), proof and verification times, and that the exposed root equals
-    the GPU witness kernel's."""
+def data_commitment_leg(pkg, n_blocks=4, n_blocks_rows=64):
+    """a circuit whose statement MEANS something: DataCommitment over (height, dataRoot) tuples with every SHA-256 compression of the RFC 6962
+    tree constrained in-circuit, public inputs = tuples + root.  Two layouts of the same statement (gadgets.py): `sha_rows` — the SHA row
+    gates (plonk_gates.h: 178 rows per compression, bit wires filled on the GPU), on n_blocks_rows blocks; `bit_decomposition` — round 2's first
+    form on the arithmetic gate alone (~65.5k gates = 3.3k rows per compression), on n_blocks blocks, kept as the comparison.  Reports circuit
+    construction (host Python), proof and verification times, and that the exposed root equals the GPU witness kernel's."""
     import importlib
     pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
     gd = importlib.import_module(graft.PKG_NAME + ".gadgets")
@@ -559,26 +560,33 @@ def data_commitment_leg(pkg, n_blocks=4):
     rc, circ, diag = pc.default_constants()
     pr.set_poseidon_constants(np.array(rc, dtype=np.uint64), np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64))
     rng = np.random.default_rng(11)
-    heights = [2_000_000 + i for i in range(n_blocks)]
-    roots = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_blocks)]
-    t0 = time.perf_counter()
-    ck, dw, public, root = gd.data_commitment_circuit(pr, heights, roots)
-    pr.sync()
-    t1 = time.perf_counter()
-    proof = ck.prove_(dw, 28, 16, public=public)
-    t2 = time.perf_counter()
-    proof = ck.prove_(dw, 28, 16, public=public)
-    t3 = time.perf_counter()
-    ok = bool(ck.verify(proof, 28, 16, public=public))
-    t4 = time.perf_counter()
-    res = {"blocks": n_blocks, "sha256_compressions": (2 * n_blocks - 1) * 2, "rows": 1 << ck.log_n, "wires": ck.n_wires, "public_inputs": len(public),
-           "build_circuit_seconds": round(t1 - t0, 3), "prove_seconds_first": round(t2 - t1, 4), "prove_seconds": round(t3 - t2, 4),
-           "verify_seconds": round(t4 - t3, 4), "verified": ok, "proof_bytes": len(proof),
-           "root_matches_gpu_witness_kernel": root == bs.data_commitment(pr, heights, roots),
-           "note": "build-defined DataCommitment statement (NOT upstream's circuit): SHA-256 Merkle tree over abi.encode(height, dataRoot) constrained "
-                   "by bit decomposition on the arithmetic gate; circuit construction is host Python"}
-    dw.free()
-    ck.free()
+
+    def one(build, nb):
+        heights = [2_000_000 + i for i in range(nb)]
+        roots = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(nb)]
+        t0 = time.perf_counter()
+        ck, dw, public, root = build(pr, heights, roots)
+        pr.sync()
+        t1 = time.perf_counter()
+        proof = ck.prove_(dw, 28, 16, public=public)
+        t2 = time.perf_counter()
+        proof = ck.prove_(dw, 28, 16, public=public)
+        t3 = time.perf_counter()
+        ok = bool(ck.verify(proof, 28, 16, public=public))
+        t4 = time.perf_counter()
+        r = {"blocks": nb, "sha256_compressions": (2 * nb - 1) * 2, "rows": 1 << ck.log_n, "wires": ck.n_wires, "public_inputs": len(public),
+             "build_circuit_seconds": round(t1 - t0, 3), "prove_seconds_first": round(t2 - t1, 4), "prove_seconds": round(t3 - t2, 4),
+             "verify_seconds": round(t4 - t3, 4), "verified": ok, "proof_bytes": len(proof),
+             "compressions_per_second_proved": round((2 * nb - 1) * 2 / (t3 - t2), 1),
+             "root_matches_gpu_witness_kernel": root == bs.data_commitment(pr, heights, roots)}
+        dw.free()
+        ck.free()
+        return r
+
+    res = dict(one(gd.data_commitment_rows_circuit, n_blocks_rows), layout="sha_rows",
+               note="build-defined DataCommitment statement (NOT upstream's circuit): SHA-256 Merkle tree over abi.encode(height, dataRoot) on the "
+                    "SHA row gates (E/A/W/ADD rows; upstream proves its SHA rounds in a separate STARK); circuit construction is host Python")
+    res["bit_decomposition"] = one(gd.data_commitment_circuit, n_blocks)
     pr.close()
     return res
 

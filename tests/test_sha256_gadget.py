@@ -168,7 +168,7 @@ def test_data_commitment_on_sha_rows(prover, oracle, pkg):
 
 @pytest.mark.gpu
 def test_recursion_over_data_commitment_proofs(prover, oracle, pkg):
-    """two DataCommitment proofs (SHA rows + Poseidon flag: header flags 3, ten constant columns) verified completely IN-CIRCUIT — the 140
+    """two DataCommitment proofs (SHA rows: header flags 2, ten constant columns) verified completely IN-CIRCUIT — the 140
     SHA-row constraints at zeta included — by one recursion proof whose public inputs are the leaves' statements, digests and the root"""
     gd, rec, bs = _mods()
     vc = importlib.import_module(graft.PKG_NAME + ".verifier_circuit")
@@ -191,8 +191,7 @@ def test_recursion_over_data_commitment_proofs(prover, oracle, pkg):
         dw.free()
         ck.free()
     W, R, n_pub = shape
-    rp = vc.RecursionProgram(prover, [p for p, _, _ in leaves], key, nq, pw, W, consts, n_routed=R, n_public=n_pub, cap_height=1, child_is_recursion=True,
-                             child_sha=True)
+    rp = vc.RecursionProgram(prover, [p for p, _, _ in leaves], key, nq, pw, W, consts, n_routed=R, n_public=n_pub, cap_height=1, child_sha=True)
     proof, public = rp.prove([p for p, _, _ in leaves], 8, 4)
     digests = [prover.proof_digest(p) for p, _, _ in leaves]
     want = [v for (_, pub, _), d in zip(leaves, digests) for v in pub + d] + rec.merkle_root_host(prover, digests)
