@@ -254,3 +254,86 @@ def reduce_tree(prover, proofs, leaf, poseidon_consts, fan_in=2, node_queries=28
         cur = [p for p, _ in nxt]
         params = dict(leaf_key=key, num_queries=node_queries, pow_bits=node_pow_bits, n_wires=136, n_routed=80, n_public=pub_len, cap_height=1,
                       poseidon_consts=poseidon_consts)
+
+
+def reduce_tree_distributed(fold_local, fold_root, my_proofs, padded_len, device=None, comm=None):
+    """The Reduce step as a two-level recursion SPREAD OVER THE RANKS.  (1) every rank folds ITS OWN leaf proofs into one node proof
+    (``fold_local(proofs) -> bytes``: a recursion proof over the leaves this GPU proved — they never leave it); (2) ONE all-gather of the
+    `world` node proofs (a second MapReduce level whose leaf r is rank r's node: the same agreement-then-gather as the Map exchange, so a rank
+    whose fold fails takes every rank out before the collective); (3) rank 0 folds the node proofs into the root
+    (``fold_root(node_proofs) -> bytes``).  The exchange carries one proof per rank instead of every leaf proof.  world must be a power of two
+    and every rank must hold the same number of leaves (one level-1 circuit).  Returns {"nodes": all node proofs in rank order, "root_proof":
+    bytes on rank 0 (the node itself when world == 1), None elsewhere}."""
+    rank, world = _world(comm)
+    if world & (world - 1):
+        raise ValueError("reduce_tree_distributed: the number of ranks must be a power of two")
+    counts = [len(my_proofs)]
+    if world > 1:
+        if comm is not None:
+            lo, hi = int(comm.allreduce_min([len(my_proofs)])[0]), -int(comm.allreduce_min([2**32 - len(my_proofs)])[0]) + 2**32
+        else:
+            t = torch.tensor([len(my_proofs), -len(my_proofs)], dtype=torch.int64, device=device if device is not None else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            lo, hi = int(t[0].item()), -int(t[1].item())
+        counts = [lo, hi]
+    if min(counts) != max(counts) or not my_proofs:
+        raise ValueError("reduce_tree_distributed: every rank must hold the same (non-zero) number of leaf proofs")
+    nodes = map_prove_gather(lambda i: fold_local(my_proofs), world, padded_len, device=device, comm=comm)      # leaf i of this level = rank i
+    if world == 1:
+        return {"nodes": nodes, "root_proof": nodes[0]}
+    return {"nodes": nodes, "root_proof": fold_root(nodes) if rank == 0 else None}
+
+
+class RecursionFolders:
+    """fold_local / fold_root for reduce_tree_distributed, as real recursions (verifier_circuit.RecursionProgram): level 1 verifies leaf proofs
+    of the circuit `leaf` = {"key", "num_queries", "pow_bits", "n_wires", ["n_routed", "n_public", "cap_height", "sha"]} in-circuit, level 2
+    verifies level-1 proofs (Poseidon-row circuits) in-circuit.  The circuits are recorded once per fan-in and kept (record_seconds says what
+    that cost); every later fold is witness evaluation + proving.  After fold_local / fold_root, `public` holds the public inputs of the
+    proof just made and `key` the verifying key it belongs to."""
+
+    def __init__(self, prover, leaf, poseidon_consts, node_queries=28, node_pow_bits=16):
+        self.prover, self.leaf, self.consts = prover, dict(leaf), poseidon_consts
+        self.nq, self.pw = node_queries, node_pow_bits
+        self.programs, self.record_seconds = {}, {}
+        self.public = self.key = None
+        self.local_key = self.local_public_len = None
+
+    def _program(self, level, proofs, **kw):
+        import importlib
+        import time
+        vc = importlib.import_module(__package__ + ".verifier_circuit")
+        k = (level, len(proofs))
+        if k not in self.programs:
+            t0 = time.perf_counter()
+            self.programs[k] = vc.RecursionProgram(self.prover, proofs, poseidon_values=self.consts, **kw)
+            self.record_seconds[k] = round(time.perf_counter() - t0, 3)
+        return self.programs[k]
+
+    def fold_local(self, proofs):
+        lf = self.leaf
+        rp = self._program(1, proofs, leaf_key=lf["key"], num_queries=lf["num_queries"], pow_bits=lf["pow_bits"], n_wires=lf["n_wires"],
+                           n_routed=lf.get("n_routed"), n_public=lf.get("n_public", 0), cap_height=lf.get("cap_height", 4),
+                           child_is_recursion=bool(lf.get("poseidon", False)), child_sha=bool(lf.get("sha", False)))
+        proof, self.public = rp.prove(proofs, self.nq, self.pw)
+        self.key = self.local_key = rp.key()
+        self.local_public_len = len(self.public)
+        return proof
+
+    def fold_root(self, node_proofs):
+        if self.local_key is None:
+            raise RuntimeError("fold_root before fold_local: the level-1 circuit (its key, its public-input count) is not known yet")
+        rp = self._program(2, node_proofs, leaf_key=self.local_key, num_queries=self.nq, pow_bits=self.pw, n_wires=rp_wires(self.programs),
+                           n_routed=80, n_public=self.local_public_len, cap_height=1, child_is_recursion=True)
+        proof, self.public = rp.prove(node_proofs, self.nq, self.pw)
+        self.key = rp.key()
+        return proof
+
+    def free(self):
+        for rp in self.programs.values():
+            rp.free()
+        self.programs = {}
+
+
+def rp_wires(programs):
+    """wire count of the level-1 recursion circuits (what the level-2 verifier is told its children have)"""
+    return next(rp.circuit.n_wires for (level, _), rp in programs.items() if level == 1)

@@ -51,6 +51,29 @@ def _worker(rank, world, port, n_leaves, q):
         ok = ok and rank == 1
     except RuntimeError as e:
         ok = ok and rank != 1 and "another rank" in str(e)
+    # Reduce as a two-level tree over the ranks: each rank folds its own leaves, ONE gather of the node blobs, rank 0 folds the root
+    if n_leaves % world == 0 and n_leaves >= world:
+        fold = lambda ps: hashlib.sha256(b"".join(ps)).digest()
+        out = mr.reduce_tree_distributed(fold, fold, [fake_proof(i) for i in mine], padded_len=64)
+        want_nodes = [fold([fake_proof(i) for i in mr.leaves_of_rank(n_leaves, r, world)]) for r in range(world)]
+        ok = ok and out["nodes"] == want_nodes and out["root_proof"] == ((fold(want_nodes) if world > 1 else want_nodes[0]) if rank == 0 else None)
+        def bad_fold(ps):
+            if rank == world - 1:
+                raise ValueError("a leaf proof does not verify")
+            return fold(ps)
+        try:
+            mr.reduce_tree_distributed(bad_fold, fold, [fake_proof(i) for i in mine], padded_len=64)
+            ok = False
+        except ValueError:
+            ok = ok and rank == world - 1
+        except RuntimeError as e:
+            ok = ok and rank != world - 1 and "another rank" in str(e)
+    elif world > 1:
+        try:
+            mr.reduce_tree_distributed(lambda ps: b"x", lambda ps: b"y", [fake_proof(i) for i in mine], padded_len=64)
+            ok = False
+        except ValueError as e:
+            ok = ok and "same" in str(e)
     # the bench's max-over-ranks time reduction
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

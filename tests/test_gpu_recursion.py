@@ -297,3 +297,45 @@ def test_recursion_on_recursion_reduce_tree(setup, pkg):
         mr.reduce_tree(prover, bad, leaf, consts, fan_in=2, node_queries=6, node_pow_bits=4)
     dw.free()
     ck.free()
+
+
+def test_reduce_tree_spread_over_ranks(setup, pkg):
+    """the two-level Reduce of mapreduce.reduce_tree_distributed with REAL recursions (RecursionFolders): what rank r does — fold its own leaf
+    proofs into a node proof with the recorded level-1 program — done here for two 'ranks' in turn, then the root fold over the two node proofs
+    (a recorded level-2 program verifying recursion proofs in-circuit); and the one-rank call, whose root is the node itself.  The recorded
+    programs are reused: a second batch costs no builder run."""
+    prover, oracle, rec, mr = setup
+    consts = poseidon_consts("small")
+    c, s, wv = bench.synthetic_circuit(prover, 9, 16)
+    ck = pkg.PlonkCircuit(prover, c, s)
+    dw = prover.to_device(wv)
+    nq, pw = 5, 3
+    leaves = [ck.prove_(dw, nq, pw) for _ in range(4)]
+    leaf = {"key": ck.cap(), "num_queries": nq, "pow_bits": pw, "n_wires": 16}
+    f = mr.RecursionFolders(prover, leaf, consts, node_queries=6, node_pow_bits=4)
+    with pytest.raises(RuntimeError):
+        f.fold_root([b""] * 2)
+    n0 = f.fold_local(leaves[:2])
+    pub0, key1 = list(f.public), f.key.copy()
+    n1 = f.fold_local(leaves[2:])
+    assert list(f.programs) == [(1, 2)] and np.array_equal(f.key, key1)              # recorded once, same circuit for every rank
+    assert prover.plonk_verify(n0, key1, 6, 4, public=pub0), prover.last_reject
+    root = f.fold_root([n0, n1])
+    assert sorted(f.programs) == [(1, 2), (2, 2)]
+    assert prover.plonk_verify(root, f.key, 6, 4, public=f.public), prover.last_reject
+    pref.verify_plonk(root, oracle, pos_consts=consts, public=f.public)
+    for p in leaves:                                                                # every leaf digest is bound by the root's statement
+        d = prover.proof_digest(p)
+        assert any(f.public[k:k + 4] == d for k in range(len(f.public) - 3))
+    root_b = f.fold_root([n1, n0])                                                  # another batch through the recorded level-2 program
+    assert prover.plonk_verify(root_b, f.key, 6, 4, public=f.public) and sorted(f.programs) == [(1, 2), (2, 2)]
+    # one rank: the exchange is a no-op and the root is this rank's node
+    out = mr.reduce_tree_distributed(f.fold_local, f.fold_root, leaves[:2], padded_len=1 << 18)
+    assert out["root_proof"] == out["nodes"][0] and prover.plonk_verify(out["root_proof"], key1, 6, 4, public=f.public)
+    bad = np.frombuffer(leaves[1], dtype="<u8").copy()
+    bad[200] ^= np.uint64(1)
+    with pytest.raises(ValueError):
+        mr.reduce_tree_distributed(f.fold_local, f.fold_root, [leaves[0], bad.tobytes()], padded_len=1 << 18)
+    f.free()
+    dw.free()
+    ck.free()
