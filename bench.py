@@ -488,33 +488,6 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
                                                                "PLONK identity")
             dwo.free()
             cko.free()
-            # ... and the Reduce as a real RECURSION: one circuit that verifies leaf proofs completely in-circuit (verifier_circuit.py) and
-            # hashes their digests into a root.  Fan-in GLP_BENCH_RECURSION_LEAVES (default 16: recording the circuit is host Python, ~0.4 s per leaf, once)
-            fan = int(os.environ.get("GLP_BENCH_RECURSION_LEAVES", "16"))
-            fan = max(1, min(1 << (fan.bit_length() - 1), len(proofs)))
-            t8 = time.perf_counter()
-            vcm = importlib.import_module(graft.PKG_NAME + ".verifier_circuit")
-            pconsts = (np.array(rc, dtype=np.uint64), np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64))
-            rp = vcm.RecursionProgram(provers[0], proofs[:fan], cks[0].cap(), 28, 16, W, pconsts)      # laid down ONCE per (leaf circuit, fan-in)
-            t9 = time.perf_counter()
-            dwv, pub_v = rp.witness(proofs[:fan])                                                     # per Reduce: host C++ witness program
-            provers[0].sync()
-            t10 = time.perf_counter()
-            rproof = rp.circuit.prove_(dwv, 28, 16, public=pub_v)
-            t11 = time.perf_counter()
-            rproof = rp.circuit.prove_(dwv, 28, 16, public=pub_v)
-            t12 = time.perf_counter()
-            rok = bool(rp.circuit.verify(rproof, 28, 16, public=pub_v))
-            t13v = time.perf_counter()
-            agg["recursive_reduce"] = dict(rp.stats, wires=rp.circuit.n_wires, record_circuit_seconds_once=round(t9 - t8, 3),
-                                           witness_seconds=round(t10 - t9, 4), prove_seconds_first=round(t11 - t10, 4), prove_seconds=round(t12 - t11, 4),
-                                           verify_seconds=round(t13v - t12, 4), verified=rok, proof_bytes=len(rproof), public_inputs=len(pub_v),
-                                           note="ONE proof whose circuit verified these leaf proofs entirely in-circuit (transcript, PoW, Merkle openings, "
-                                                "FRI, PLONK identity) and hashed their digests to a root; its verifier needs no leaf proof.  The circuit is "
-                                                "recorded once by the Python builder; every Reduce after that = witness_seconds (glp_witness_eval, host C++, "
-                                                "+ upload + Poseidon-row fill on the GPU) + prove_seconds")
-            dwv.free()
-            rp.free()
             # ... and as a TREE: pairs of leaves verified by level-1 nodes, pairs of level-1 (recursion) proofs verified by the level-2 node
             t13 = time.perf_counter()
             tree = mr.reduce_tree(provers[0], proofs[:4], {"key": cks[0].cap(), "num_queries": 28, "pow_bits": 16, "n_wires": W},
@@ -525,6 +498,64 @@ def mapreduce_leg(pkg, rank, local_rank, world, leaves_per_rank=16, log_n=16, W=
                                               "root_verifies": bool(provers[0].plonk_verify(tree["root_proof"], tree["key"], 28, 16, public=tree["public"]))}
         except Exception as e:  # noqa: BLE001
             agg = dict(agg or {}, error=f"{type(e).__name__}: {e}"[:200])
+    # ... and the Reduce as a real RECURSION spread over the ranks (mapreduce.reduce_tree_distributed): every rank folds the leaf proofs IT proved
+    # into one node proof (a circuit that verifies them completely in-circuit: verifier_circuit.py), ONE all-gather of the node proofs, rank 0
+    # folds them into the root.  One rank: the root is the node.  Every rank takes part (collectives inside); GLP_BENCH_TREE=0 skips it.
+    rr = None
+    pow2 = lambda v: v >= 1 and v & (v - 1) == 0
+    if all_ok and pow2(world) and pow2(leaves_per_rank) and os.environ.get("GLP_BENCH_TREE", "1") != "0":
+        pconsts = (np.array(rc, dtype=np.uint64), np.array(circ, dtype=np.uint64), np.array(diag, dtype=np.uint64))
+        folders = mr.RecursionFolders(provers[0], {"key": cks[0].cap(), "num_queries": 28, "pow_bits": 16, "n_wires": W}, pconsts)
+        mine = [proofs[i] for i in mr.leaves_of_rank(n_leaves, rank, world)]
+        root_err = []
+
+        def fold_root(nodes):                       # rank 0 only, after the collectives: a failure here must not unbalance the ranks
+            try:
+                return folders.fold_root(nodes)
+            except Exception as e:  # noqa: BLE001
+                root_err.append(f"{type(e).__name__}: {e}"[:200])
+                return None
+        try:
+            t0 = time.perf_counter()
+            out = mr.reduce_tree_distributed(folders.fold_local, fold_root, mine, 1 << 18, device=dev)   # records the circuits on first use
+            t_first = time.perf_counter() - t0
+            # steady state: the same steps once more with the recorded programs (local work timed locally; the exchange alone, on every rank)
+            t1 = time.perf_counter()
+            rp1 = folders.programs[(1, len(mine))]
+            dwv, pub_v = rp1.witness(mine)
+            provers[0].sync()
+            t2 = time.perf_counter()
+            node = rp1.circuit.prove_(dwv, 28, 16, public=pub_v)
+            t3 = time.perf_counter()
+            dwv.free()
+            nodes = mr.allgather_leaf_proofs([(rank, node)], world, 1 << 18, device=dev)
+            t4 = time.perf_counter()
+            rr = dict(rp1.stats, wires=rp1.circuit.n_wires, ranks=world, leaves_per_rank=len(mine),
+                      record_circuit_seconds_once=folders.record_seconds.get((1, len(mine))), witness_seconds=round(t2 - t1, 4),
+                      prove_seconds=round(t3 - t2, 4), exchange_node_proofs_seconds=round(t4 - t3, 4), node_proof_bytes=len(node),
+                      first_call_seconds_including_recording=round(t_first, 3))
+            if rank == 0:
+                ok_node = bool(provers[0].plonk_verify(out["nodes"][0], folders.local_key, 28, 16, public=pkg.proof_public_inputs(out["nodes"][0])))
+                rr.update(node_verifies=ok_node, public_inputs=len(pub_v))
+                if world > 1 and not root_err:
+                    t5 = time.perf_counter()
+                    root2 = folders.fold_root(nodes)
+                    t6 = time.perf_counter()
+                    rp2 = folders.programs[(2, world)]
+                    rr["root"] = dict(rp2.stats, record_circuit_seconds_once=folders.record_seconds.get((2, world)),
+                                      witness_and_prove_seconds=round(t6 - t5, 4), proof_bytes=len(root2), public_inputs=len(folders.public),
+                                      verified=bool(provers[0].plonk_verify(root2, folders.key, 28, 16, public=folders.public)))
+                elif root_err:
+                    rr["root"] = {"error": root_err[0]}
+                rr["note"] = ("Reduce as a recursion: each rank's node proof verifies that rank's leaf proofs entirely in-circuit (transcript, PoW, Merkle "
+                              "openings, FRI, PLONK identity) and hashes their digests to a root; with more ranks ONE all-gather of the node proofs and a "
+                              "root proof on rank 0 that verifies them in-circuit.  Circuits are recorded once (host builder); every Reduce after that = "
+                              "witness_seconds (glp_witness_eval_mt on host threads + on-device placement) + prove_seconds (+ exchange + root)")
+        except Exception as e:  # noqa: BLE001 — raised on EVERY rank (agreement before the collectives) or on none
+            rr = {"error": f"{type(e).__name__}: {e}"[:200]}
+        folders.free()
+    if agg is not None and rr is not None:
+        agg["recursive_reduce"] = rr
     if world > 1:
         tt = torch.tensor([dt, dt_red], dtype=torch.float64, device=_coll_device())
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
