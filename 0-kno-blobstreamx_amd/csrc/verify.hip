@@ -781,7 +781,11 @@ extern "C" int glp_witness_eval_mt(const uint64_t* h_rc, const uint64_t* h_mds_c
         };
         const size_t nt = n_threads < n_seg ? n_threads : n_seg;
         std::vector<std::thread> pool;
-        for (size_t t = 1; t < nt; t++) pool.emplace_back(worker);
+        try {
+            for (size_t t = 1; t < nt; t++) pool.emplace_back(worker);
+        } catch (...) {
+            // the host refused another thread: the ones that started (and this one) share the segments — no exception crosses the C ABI
+        }
         worker();
         for (auto& t : pool) t.join();
         if (status.load() != GLP_OK) return status.load();
