@@ -612,25 +612,34 @@ class RecursionProgram:
     (ValueError): some copy constraint of the verifier circuit fails on its witness."""
 
     def __init__(self, prover, sample_proofs, leaf_key, num_queries, pow_bits, n_wires, poseidon_values, n_routed=None, n_public=0, cap_height=4,
-                 child_is_recursion=False, child_sha=False):
+                 child_is_recursion=False, child_sha=False, combine=None, builder_wires=136):
+        """combine(b, outs) -> [public input variables]: what the node states about its children, laid down after their verification
+        (outs[k] = {"public": child k's public-input variables, "digest": its 4 digest variables}).  Default: every child's public inputs and
+        digest, then the Poseidon root of the digests.  builder_wires: wire count of THIS circuit (144 when combine uses SHA rows)."""
         from .recursion import CircuitBuilder
         n = len(sample_proofs)
         assert n >= 1 and n & (n - 1) == 0, "a power-of-two number of proofs"
         self.prover, self.consts = prover, poseidon_values
-        b = CircuitBuilder(prover)
-        level = []
+        b = CircuitBuilder(prover, n_wires=builder_wires)
+        outs = []
         for k, proof in enumerate(sample_proofs):
             b.begin_segment()            # one proof's verifier depends on constants and on itself: the witness evaluator runs them in parallel
-            out = verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height,
-                                    poseidon_values if child_is_recursion else None, proof_id=k, sha=child_sha)
+            outs.append(verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height,
+                                          poseidon_values if child_is_recursion else None, proof_id=k, sha=child_sha))
             b.end_segment()
-            for v in out["public"] + out["digest"]:
+        if combine is None:
+            level = []
+            for out in outs:
+                for v in out["public"] + out["digest"]:
+                    b.public_input(v)
+                level.append(out["digest"])
+            while len(level) > 1:
+                level = [b.two_to_one(level[2 * k], level[2 * k + 1]) for k in range(len(level) // 2)]
+            for v in level[0]:
                 b.public_input(v)
-            level.append(out["digest"])
-        while len(level) > 1:
-            level = [b.two_to_one(level[2 * k], level[2 * k + 1]) for k in range(len(level) // 2)]
-        for v in level[0]:
-            b.public_input(v)
+        else:
+            for v in combine(b, outs):
+                b.public_input(v)
         self.program = b.program()
         self.circuit = self.program.setup(prover)
         self.stats = dict(self.program.stats, leaves=n)

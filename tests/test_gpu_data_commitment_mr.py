@@ -1,0 +1,91 @@
+"""DataCommitment over a block range as a MapReduce of proofs (data_commitment_mr.py): leaves on the SHA row gates, nodes that verify their
+children in-circuit and combine the statements (SHA-256 inner nodes over the subtree roots, Poseidon tree over the tuple digests).  The root
+proof's commitment equals hashlib's RFC 6962 root over the whole range, and the proof verifies only for the tuples it was made from."""
+import hashlib
+import importlib
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import plonk_ref as pref  # noqa: E402
+from conftest import poseidon_consts, ptr  # noqa: E402
+import __graft_entry__ as graft  # noqa: E402
+
+
+def _root(heights, roots):
+    lvl = [hashlib.sha256(b"\x00" + int(h).to_bytes(32, "big") + r).digest() for h, r in zip(heights, roots)]
+    while len(lvl) > 1:
+        lvl = [hashlib.sha256(b"\x01" + lvl[i] + lvl[i + 1]).digest() for i in range(0, len(lvl), 2)]
+    return lvl[0]
+
+
+def test_tuples_digest_is_a_poseidon_tree(oracle):
+    """host restatement of D: hash_no_pad per leaf (oracle permutation), binary two_to_one tree above"""
+    graft.load_package()
+    dm = importlib.import_module(graft.PKG_NAME + ".data_commitment_mr")
+    consts = poseidon_consts("small")
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    rng = np.random.default_rng(8)
+    hs = list(range(50, 58))
+    rs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in hs]
+
+    def perm(state):
+        s = np.array(state, dtype=np.uint64)
+        oracle.orc_poseidon_permute(ptr(s))
+        return [int(v) for v in s]
+    leaves = []
+    for k in range(0, 8, 2):
+        words = [w for h, r in zip(hs[k:k + 2], rs[k:k + 2]) for w in dm.tuple_words(h, r)]
+        st = [0] * 12
+        for off in range(0, len(words), 8):
+            st = perm(words[off:off + 8] + st[8:])
+        leaves.append(st[:4])
+    while len(leaves) > 1:
+        leaves = [perm(leaves[k] + leaves[k + 1] + [0] * 4)[:4] for k in range(0, len(leaves), 2)]
+    assert dm.tuples_digest(consts, hs, rs, 2) == leaves[0]
+
+
+@pytest.mark.gpu
+def test_data_commitment_of_a_range_by_mapreduce(prover, oracle, pkg):
+    dm = importlib.import_module(graft.PKG_NAME + ".data_commitment_mr")
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    rng = np.random.default_rng(4100)
+    heights = [7_000_000 + k for k in range(8)]
+    roots = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in heights]
+    mr = dm.DataCommitmentMapReduce(prover, consts, leaf_blocks=2, fan_in=2, num_queries=6, pow_bits=4)
+    out = mr.prove_range(heights, roots)
+    assert out["leaves"] == 4 and [lv["nodes"] for lv in out["levels"]] == [2, 1]
+    assert out["commitment"] == _root(heights, roots)
+    assert len(out["public"]) == 12 and out["public"][8:] == dm.tuples_digest(consts, heights, roots, 2)
+    assert mr.verify(out["root_proof"], out["key"], heights, roots, out["commitment"]), prover.last_reject
+    pref.verify_plonk(out["root_proof"], oracle, pos_consts=consts, public=out["public"])
+    # another commitment, another tuple, another order: different statements
+    wrong = bytearray(out["commitment"])
+    wrong[5] ^= 1
+    assert not mr.verify(out["root_proof"], out["key"], heights, roots, bytes(wrong))
+    other = list(roots)
+    other[3] = bytes(32)
+    assert not mr.verify(out["root_proof"], out["key"], heights, other, out["commitment"])
+    assert not mr.verify(out["root_proof"], out["key"], heights[::-1], roots[::-1], out["commitment"])
+    # a second range through the recorded programs (no builder run): leaf + both node levels are replays
+    rec_before = dict(mr.record_seconds)
+    h2 = [9_000 + 3 * k for k in range(8)]
+    r2 = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in h2]
+    out2 = mr.prove_range(h2, r2)
+    assert mr.record_seconds == rec_before and out2["commitment"] == _root(h2, r2)
+    assert mr.verify(out2["root_proof"], out2["key"], h2, r2, out2["commitment"]) and np.array_equal(out2["key"], out["key"])
+    assert not mr.verify(out2["root_proof"], out2["key"], heights, roots, out["commitment"])
+    # a leaf proof with a flipped word cannot be folded
+    leaf, _ = mr.prove_leaf(heights[:2], roots[:2])
+    leaf_b, _ = mr.prove_leaf(heights[2:4], roots[2:4])
+    bad = np.frombuffer(leaf_b, dtype="<u8").copy()
+    bad[len(bad) // 3] ^= np.uint64(1)
+    with pytest.raises(ValueError):
+        mr.reduce([leaf, bad.tobytes()])
+    mr.free()
