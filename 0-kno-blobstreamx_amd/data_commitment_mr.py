@@ -116,9 +116,10 @@ class DataCommitmentMapReduce:
             self.record_seconds[f"node_level{level}_fan{len(proofs)}"] = round(time.perf_counter() - t0, 3)
         return self.nodes[k]
 
-    def reduce(self, proofs, timings=None):
-        """fold child proofs level by level; returns (root proof, its public inputs, its verifying key)"""
-        cur, key, level, public = list(proofs), self.leaf_circuit.cap(), 1, None
+    def reduce(self, proofs, timings=None, child_key=None, level=1):
+        """fold child proofs level by level; returns (root proof, its public inputs, its verifying key, the next level number).  child_key /
+        level: where the fold starts (default: leaf proofs at level 1; a later start folds node proofs made elsewhere, e.g. on other ranks)"""
+        cur, key, public = list(proofs), (self.leaf_circuit.cap() if child_key is None else child_key), None
         while True:
             fan = min(self.fan_in, len(cur))
             if len(cur) % fan or fan & (fan - 1):
@@ -132,10 +133,51 @@ class DataCommitmentMapReduce:
             if timings is not None:
                 timings.append({"level": level, "nodes": len(nxt), "fan_in": fan, "rows": rp.stats["rows"],
                                 "seconds_including_first_recording": round(time.perf_counter() - t0, 4)})
-            key = rp.key()
+            key, level = rp.key(), level + 1
             if len(nxt) == 1:
-                return nxt[0], public, key
-            cur, level = nxt, level + 1
+                return nxt[0], public, key, level
+            cur = nxt
+
+    def prove_range_distributed(self, heights, data_roots, device=None, comm=None):
+        """the same proof with the work spread over the ranks (mapreduce.reduce_tree_distributed): rank r proves the leaves of the r-th CONTIGUOUS
+        part of the range and folds them into one node proof on its own GPU, ONE all-gather carries the `world` node proofs, rank 0 folds them into
+        the root.  Every rank passes the whole range (it only touches its part).  Returns the prove_range dict on rank 0 (root_proof None elsewhere)."""
+        mrm = importlib.import_module(__package__ + ".mapreduce")
+        rank, world = mrm._world(comm)
+        n = len(heights)
+        n_leaves = n // self.leaf_blocks
+        if n % self.leaf_blocks or n_leaves % world or len(data_roots) != n:
+            raise ValueError("the range is not a whole number of leaves per rank")
+        per = n_leaves // world
+        lo = rank * per * self.leaf_blocks
+        state, levels = {}, []
+
+        def fold_local(_):
+            t0 = time.perf_counter()
+            leaves = [self.prove_leaf(heights[k:k + self.leaf_blocks], data_roots[k:k + self.leaf_blocks])[0]
+                      for k in range(lo, lo + per * self.leaf_blocks, self.leaf_blocks)]
+            state["map_seconds"] = round(time.perf_counter() - t0, 4)
+            if per == 1:
+                state.update(key=self.leaf_circuit.cap(), level=1, public=None)
+                return leaves[0]
+            proof, public, key, level = self.reduce(leaves, levels)
+            state.update(key=key, level=level, public=public)
+            return proof
+
+        def fold_root(nodes):
+            proof, public, key, _ = self.reduce(nodes, levels, child_key=state["key"], level=state["level"])
+            state.update(key=key, public=public)
+            return proof
+        t0 = time.perf_counter()
+        out = mrm.reduce_tree_distributed(fold_local, fold_root, [b""] * per, 1 << 18, device=device, comm=comm)
+        root = out["root_proof"]
+        public = state["public"]
+        if root is not None and public is None:
+            public = [int(v) for v in importlib.import_module(__package__).proof_public_inputs(root)]
+        return {"root_proof": root, "public": public, "key": state["key"] if root is not None else None, "leaves": n_leaves, "ranks": world,
+                "map_seconds": state["map_seconds"], "seconds": round(time.perf_counter() - t0, 4), "levels": levels,
+                "record_seconds": dict(self.record_seconds),
+                "commitment": b"".join(struct.pack(">I", v) for v in public[:8]) if root is not None else None}
 
     def prove_range(self, heights, data_roots):
         n = len(heights)
@@ -148,7 +190,7 @@ class DataCommitmentMapReduce:
         if len(leaves) == 1:
             root_proof, public, key = leaves[0], [int(v) for v in importlib.import_module(__package__).proof_public_inputs(leaves[0])], self.leaf_circuit.cap()
         else:
-            root_proof, public, key = self.reduce(leaves, levels)
+            root_proof, public, key, _ = self.reduce(leaves, levels)
         t2 = time.perf_counter()
         return {"root_proof": root_proof, "public": public, "key": key, "leaves": len(leaves), "map_seconds": round(t1 - t0, 4),
                 "reduce_seconds": round(t2 - t1, 4), "levels": levels, "record_seconds": dict(self.record_seconds),

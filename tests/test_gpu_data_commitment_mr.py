@@ -88,4 +88,17 @@ def test_data_commitment_of_a_range_by_mapreduce(prover, oracle, pkg):
     bad[len(bad) // 3] ^= np.uint64(1)
     with pytest.raises(ValueError):
         mr.reduce([leaf, bad.tobytes()])
+    # the distributed form on one rank (the exchange is a no-op): same proof shape, same commitment
+    out3 = mr.prove_range_distributed(heights, roots)
+    assert out3["commitment"] == out["commitment"] and out3["ranks"] == 1 and np.array_equal(out3["key"], out["key"])
+    assert mr.verify(out3["root_proof"], out3["key"], heights, roots, out3["commitment"])
+    # ... and what two ranks would do, in turn: each folds its contiguous half, then the root over the two node proofs
+    halves = []
+    for r in range(2):
+        lv = [mr.prove_leaf(heights[k:k + 2], roots[k:k + 2])[0] for k in range(4 * r, 4 * r + 4, 2)]
+        node, _, key1, lvl = mr.reduce(lv)
+        halves.append(node)
+    root4, pub4, key4, _ = mr.reduce(halves, child_key=key1, level=lvl)
+    assert np.array_equal(key4, out["key"]) and pub4 == out["public"]
+    assert mr.verify(root4, key4, heights, roots, out["commitment"])
     mr.free()
