@@ -65,9 +65,12 @@ class DataCommitmentMapReduce:
     powers of two; the number of leaves must be fan_in^k * m with the last level's fan-in m a power of two <= fan_in (e.g. 64 leaves, fan_in 16:
     4 nodes of 16, then a root of 4)."""
 
-    def __init__(self, prover, poseidon_consts, leaf_blocks=64, fan_in=8, num_queries=28, pow_bits=16):
+    def __init__(self, prover, poseidon_consts, leaf_blocks=64, fan_in=8, num_queries=28, pow_bits=16, map_provers=()):
+        """map_provers: further Provers on the same GPU (their Poseidon constants set): the Map step then proves leaves on all of them at once,
+        one host thread each (the latency-bound phases of one leaf proof overlap the throughput-bound phases of another, as in mapreduce.py)"""
         assert leaf_blocks >= 1 and leaf_blocks & (leaf_blocks - 1) == 0 and fan_in >= 2 and fan_in & (fan_in - 1) == 0
         self.prover, self.consts = prover, tuple(np.ascontiguousarray(a, dtype=np.uint64) for a in poseidon_consts)
+        self.map_provers, self.map_circuits = list(map_provers), []
         self.leaf_blocks, self.fan_in, self.nq, self.pw = leaf_blocks, fan_in, num_queries, pow_bits
         self.leaf_program = self.leaf_circuit = None
         self.nodes = {}                 # (level, fan-in) -> RecursionProgram
@@ -90,20 +93,41 @@ class DataCommitmentMapReduce:
             b.public_input(v)
         self.leaf_program = b.program()
         self.leaf_circuit = self.leaf_program.setup(self.prover)
+        self.map_circuits = [self.leaf_program.setup(p) for p in self.map_provers]          # the same circuit (same key) committed on each ctx
         self.record_seconds["leaf"] = round(time.perf_counter() - t0, 3)
 
-    def prove_leaf(self, heights, data_roots):
-        """(proof, public) for one leaf's subrange, through the recorded leaf program"""
+    def prove_leaf(self, heights, data_roots, which=0):
+        """(proof, public) for one leaf's subrange, through the recorded leaf program; which: 0 = the main prover, k = map_provers[k-1]"""
         assert len(heights) == len(data_roots) == self.leaf_blocks
         if self.leaf_program is None:
             self._record_leaf()
+        prover, circuit = (self.prover, self.leaf_circuit) if which == 0 else (self.map_provers[which - 1], self.map_circuits[which - 1])
         inputs = [w for h, r in zip(heights, data_roots) for w in tuple_words(h, r)]
-        vals = self.leaf_program.evaluate(self.consts, inputs)
-        dw, public = self.leaf_program.device_witness(self.prover, vals)
+        vals = self.leaf_program.evaluate(self.consts, inputs, threads=1)
+        dw, public = self.leaf_program.device_witness(prover, vals)
         try:
-            return self.leaf_circuit.prove_(dw, self.nq, self.pw, public=public), public
+            return circuit.prove_(dw, self.nq, self.pw, public=public), public
         finally:
             dw.free()
+
+    def prove_leaves(self, heights, data_roots):
+        """the Map step of a (sub)range: its leaf proofs in order, on every prover this object has"""
+        if self.leaf_program is None:
+            self._record_leaf()
+        B = self.leaf_blocks
+        starts = list(range(0, len(heights), B))
+        n_workers = 1 + len(self.map_provers)
+        if n_workers == 1 or len(starts) == 1:
+            return [self.prove_leaf(heights[k:k + B], data_roots[k:k + B])[0] for k in starts]
+        from concurrent.futures import ThreadPoolExecutor
+
+        def work(w):
+            if w:
+                self.map_provers[w - 1].bind_thread()
+            return [(k, self.prove_leaf(heights[k:k + B], data_roots[k:k + B], which=w)[0]) for k in starts[w::n_workers]]
+        with ThreadPoolExecutor(n_workers) as ex:
+            done = sorted((p for f in [ex.submit(work, w) for w in range(n_workers)] for p in f.result()), key=lambda t: t[0])
+        return [p for _, p in done]
 
     # ---- Reduce -------------------------------------------------------------------------------------------------------------------
     def _node(self, level, proofs, child_key):
@@ -154,8 +178,8 @@ class DataCommitmentMapReduce:
 
         def fold_local(_):
             t0 = time.perf_counter()
-            leaves = [self.prove_leaf(heights[k:k + self.leaf_blocks], data_roots[k:k + self.leaf_blocks])[0]
-                      for k in range(lo, lo + per * self.leaf_blocks, self.leaf_blocks)]
+            hi = lo + per * self.leaf_blocks
+            leaves = self.prove_leaves(heights[lo:hi], data_roots[lo:hi])
             state["map_seconds"] = round(time.perf_counter() - t0, 4)
             if per == 1:
                 state.update(key=self.leaf_circuit.cap(), level=1, public=None)
@@ -184,7 +208,7 @@ class DataCommitmentMapReduce:
         if n % self.leaf_blocks or len(data_roots) != n:
             raise ValueError("the range is not a whole number of leaves")
         t0 = time.perf_counter()
-        leaves = [self.prove_leaf(heights[k:k + self.leaf_blocks], data_roots[k:k + self.leaf_blocks])[0] for k in range(0, n, self.leaf_blocks)]
+        leaves = self.prove_leaves(heights, data_roots)
         t1 = time.perf_counter()
         levels = []
         if len(leaves) == 1:
@@ -207,6 +231,9 @@ class DataCommitmentMapReduce:
             rp.free()
         self.nodes = {}
         if self.leaf_circuit is not None:
-            self.leaf_program.release(self.prover)
+            self.leaf_program.release()
+            for c in self.map_circuits:
+                c.free()
+            self.map_circuits = []
             self.leaf_circuit.free()
             self.leaf_circuit = self.leaf_program = None

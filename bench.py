@@ -637,8 +637,12 @@ def data_commitment_range_leg(pkg, rank, local_rank, world, blocks=4096, leaf_bl
     pr = pkg.Prover(_gpu_index(local_rank))
     pr.set_poseidon_constants(*consts)
     dev = torch.device("cuda", local_rank) if (world > 1 and not _rehearsal()) else None
-    mr = dm.DataCommitmentMapReduce(pr, consts, leaf_blocks=leaf_blocks, fan_in=fan_in)
-    res = {"blocks": blocks, "leaf_blocks": leaf_blocks, "fan_in": fan_in, "ranks": world, "sha256_compressions": (2 * blocks - 1) * 2}
+    extra = [pkg.Prover(_gpu_index(local_rank)) for _ in range(2)]        # 3 concurrent provers per GPU for the Map step (as in mapreduce_leg)
+    for p in extra:
+        p.set_poseidon_constants(*consts)
+    mr = dm.DataCommitmentMapReduce(pr, consts, leaf_blocks=leaf_blocks, fan_in=fan_in, map_provers=extra)
+    res = {"blocks": blocks, "leaf_blocks": leaf_blocks, "fan_in": fan_in, "ranks": world, "map_provers_per_gpu": 3,
+           "sha256_compressions": (2 * blocks - 1) * 2}
     rng = np.random.default_rng(12)                                  # the same range on every rank
     for run in ("first_run_records_circuits", "steady_state"):
         hs = [3_000_000 + i for i in range(blocks)]
@@ -672,6 +676,8 @@ def data_commitment_range_leg(pkg, rank, local_rank, world, blocks=4096, leaf_bl
                        "abi.encode(height, dataRoot) of the whole range + a Poseidon digest tree of the tuples; every compression constrained (SHA row gates), "
                        "every child proof verified in-circuit; seconds = Map + Reduce, whole job")
     mr.free()
+    for p in extra:
+        p.close()
     pr.close()
     return res
 

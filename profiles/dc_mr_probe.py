@@ -36,8 +36,12 @@ def root(hs, rs):
     return lvl[0]
 
 
-mr = dm.DataCommitmentMapReduce(pr, consts, leaf_blocks=leaf_blocks, fan_in=fan_in)
-res = {"blocks": blocks, "leaf_blocks": leaf_blocks, "fan_in": fan_in}
+n_extra = int(os.environ.get("DC_MR_EXTRA_PROVERS", "2"))
+extra = [pkg.Prover(0) for _ in range(n_extra)]
+for p in extra:
+    p.set_poseidon_constants(*consts)
+mr = dm.DataCommitmentMapReduce(pr, consts, leaf_blocks=leaf_blocks, fan_in=fan_in, map_provers=extra)
+res = {"blocks": blocks, "leaf_blocks": leaf_blocks, "fan_in": fan_in, "map_provers": 1 + n_extra}
 for run in ("first_run_records_circuits", "steady_state"):
     hs, rs = rnd_range()
     t0 = time.perf_counter()
