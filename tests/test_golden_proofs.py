@@ -215,3 +215,45 @@ def test_gpu_prover_reproduces_golden_bytes(pkg, prover, golden):
     prover.set_poseidon_constants(rc, circ, diag)
     assert prover.plonk_verify(bytes.fromhex(golden["plonk"]["proof"]), np.array(golden["plonk"]["circuit_cap"], dtype=np.uint64), 8, 4)
     assert prover.fri_verify(bytes.fromhex(golden["fri"]["proof"]), 6, 5)
+
+
+def test_host_verifiers_survive_truncated_and_garbage_proofs(pkg, golden):
+    """robustness of the parsers (they read lengths and counts from untrusted bytes): every golden proof cut at many lengths, padded with
+    junk, filled with random words or with extreme header fields is REFUSED — no crash, no acceptance, no huge allocation"""
+    consts = poseidon_consts("small")
+    rng = np.random.default_rng(99)
+    for name in ("plonk", "gates", "sha"):
+        g = golden[name]
+        proof, cap = bytes.fromhex(g["proof"]), np.array(g["circuit_cap"], dtype=np.uint64)
+        verify = lambda b: pkg.plonk_verify_host(consts, b, cap, 1, 0, public=pkg.UNBOUND)[0]
+        assert verify(proof)
+        for cut in list(range(0, 200, 8)) + list(range(200, len(proof), 8 * 53)) + [len(proof) - 8]:
+            assert not verify(proof[:cut]), f"{name}: accepted a proof cut to {cut} bytes"
+        assert not verify(proof + bytes(8)) and not verify(proof + proof[:64])
+        words = np.frombuffer(proof, dtype="<u8")
+        for pos, val in ((1, 2**63), (1, 25), (2, 2**32), (3, 2**40), (5, 2**20), (6, 2**62), (7, 255)):       # log_n, W, R, cap_h, n_public, flags
+            bad = words.copy()
+            bad[pos] = np.uint64(val)
+            assert not verify(bad.tobytes()), f"{name}: header word {pos} = {val}"
+        for _ in range(20):
+            junk = rng.integers(0, 2**63, len(words), dtype=np.uint64)
+            junk[0] = words[0]
+            junk[1:8] = words[1:8]                                                  # a plausible header in front of random words
+            assert not verify(junk.tobytes())
+    fri = bytes.fromhex(golden["fri"]["proof"])
+    fverify = lambda b: pkg.fri_verify_host(consts, b, 1, 0, 1)[0]
+    assert fverify(fri)
+    for cut in list(range(0, 160, 8)) + list(range(160, len(fri), 8 * 41)):
+        assert not fverify(fri[:cut])
+    fw = np.frombuffer(fri, dtype="<u8")
+    for pos in range(1, 24):
+        for val in (2**63, 2**32 + 1, 0):
+            bad = fw.copy()
+            if int(bad[pos]) == val:
+                continue
+            bad[pos] = np.uint64(val)
+            assert not fverify(bad.tobytes()), f"fri header word {pos} = {val}"
+    # digests / public-input readers on short input
+    for cut in (0, 8, 56, 64, 72):
+        with pytest.raises(Exception):
+            pkg.proof_digest_host(consts, proof[:cut])
