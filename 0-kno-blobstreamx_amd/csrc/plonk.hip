@@ -249,7 +249,9 @@ static int quotient_evals(glp_ctx* c, glp_plonk_circuit* ck, const u64* wires_ld
     qa.n_inv = gl_inv(n % GL_P);
     qa.inv_xm1 = ck->inv_xm1.u();
     qa.out = quot_rev;
-    if (ck->flags & GLP_CIRCUIT_POSEIDON_GATE)
+    if ((ck->flags & GLP_CIRCUIT_POSEIDON_GATE) && c->hash->small_mds && !getenv("GLP_K7_GENERIC_MDS"))
+        hipLaunchKernelGGL((glp_quotient_kernel<true, true>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa);
+    else if (ck->flags & GLP_CIRCUIT_POSEIDON_GATE)
         hipLaunchKernelGGL(glp_quotient_kernel<true>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa);
     else
         hipLaunchKernelGGL(glp_quotient_kernel<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qa);

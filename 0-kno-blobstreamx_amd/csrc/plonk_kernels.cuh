@@ -181,7 +181,39 @@ struct GlpQuotientArgs {
     const u64* inv_xm1;            // [N] 1 / (x_i - 1), bit-reversed order (built once per domain)
     u64* out;                      // [NCHAL][N]
 };
-template <bool POS>
+// The 118 Poseidon-row constraints in the base field with the permutation kernels' arithmetic (hash_kernels.cuh): S-boxes on arbitrary u64
+// representatives, the MDS layer on its small-integer accumulators (SMALL: every entry < 2^24 — 12 x 12 multiply-adds per round cost ~1.4 VALU each
+// instead of a full field multiplication and addition, the difference between 95k and 6k VALU per LDE point), values canonicalised only where
+// a constraint is emitted.  The same walk, in the same order, as glp_poseidon_gate_constraints<GlpGateBase> (which stays the definition: the
+// verifier uses it in the extension field, K7 uses it when the MDS is not small, and the parity tests compare both paths with the restatement).
+template <bool SMALL, class WireFn, class EmitFn>
+GL_HD void glp_poseidon_gate_constraints_fast(WireFn&& wire, const u64* rc, const u64* circ, const u64* diag, EmitFn&& emit) {
+    u64 s[12];
+    for (int i = 0; i < 12; i++) s[i] = gl_add(wire(i), rc[i]);
+    int rnd = 0, aw = 24;
+    for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
+        if (r > 0) {
+            for (int i = 0; i < 12; i++) { const u64 v = wire(aw + i); emit(gl_sub(v, gl_canon(s[i]))); s[i] = v; }
+            aw += 12;
+        }
+        for (int i = 0; i < 12; i++) s[i] = glp_sbox7(s[i]);
+        glp_mds_layer<SMALL>(s, circ, diag, rc + (rnd + 1) * 12);
+    }
+    for (int r = 0; r < GLP_POS_PARTIAL; r++, rnd++) {
+        const u64 p = wire(aw++);
+        emit(gl_sub(p, gl_canon(s[0])));
+        s[0] = glp_sbox7(p);
+        glp_mds_layer<SMALL>(s, circ, diag, rc + (rnd + 1) * 12);
+    }
+    for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
+        for (int i = 0; i < 12; i++) { const u64 v = wire(aw + i); emit(gl_sub(v, gl_canon(s[i]))); s[i] = glp_sbox7(v); }
+        aw += 12;
+        glp_mds_layer<SMALL>(s, circ, diag, rnd + 1 < GLP_POS_ROUNDS ? rc + (rnd + 1) * 12 : nullptr);
+    }
+    for (int i = 0; i < 12; i++) emit(gl_sub(wire(12 + i), gl_canon(s[i])));
+}
+
+template <bool POS, bool SMALL_MDS = false>
 __global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
     const u32 log_N = a.log_n + a.rate_bits;
     const u64 N = 1ull << log_N;
@@ -246,12 +278,13 @@ __global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
         for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) pacc[t] = 0;
         u32 k = 0;
         const u64* ap0 = a.alpha_pow + 2 + 3 * M;
-        glp_poseidon_gate_constraints<GlpGateBase>([&](int j) -> u64 { return a.wires[(u64)j * N + i]; }, a.pos_consts, a.pos_consts + 360,
-                                                   a.pos_consts + 372, [&](u64 con) {
-                                                       for (u32 t = 0; t < GLP_PLONK_NCHAL; t++)
-                                                           pacc[t] = gl_add(pacc[t], gl_mul(ap0[(u64)t * a.n_con + k], con));
-                                                       k++;
-                                                   });
+        auto wire = [&](int j) -> u64 { return a.wires[(u64)j * N + i]; };
+        auto emit = [&](u64 con) {
+            for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) pacc[t] = gl_add(pacc[t], gl_mul(ap0[(u64)t * a.n_con + k], con));
+            k++;
+        };
+        if constexpr (SMALL_MDS) glp_poseidon_gate_constraints_fast<true>(wire, a.pos_consts, a.pos_consts + 360, a.pos_consts + 372, emit);
+        else glp_poseidon_gate_constraints<GlpGateBase>(wire, a.pos_consts, a.pos_consts + 360, a.pos_consts + 372, emit);
         for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) acc[t] = gl_add(acc[t], gl_mul(q_pos, pacc[t]));
     }
     for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {

@@ -325,8 +325,26 @@ extern "C" int emu_plonk_quotient(const u64* consts, const u64* sigmas, const u6
     const u64 sn = gl_pow(7, n), wr = gl_root_of_unity(rb);
     for (u32 k = 0; k < (1u << rb); k++) qa.zh_inv[k] = gl_inv(gl_sub(gl_mul(sn, gl_pow(wr, k)), 1));
     qa.n_inv = gl_inv(n % GL_P); qa.inv_xm1 = inv.data(); qa.out = out;
-    if (flags & GLP_CIRCUIT_POSEIDON_GATE) glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<true>(qa); });
-    else glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<false>(qa); });
+    if (flags & GLP_CIRCUIT_POSEIDON_GATE) {
+        // the product picks the small-integer MDS form of the row constraints when the constants allow it: run that one, and hold it against
+        // the generic form (the gate's definition) point for point
+        bool small = true;
+        unsigned __int128 sum = 0;
+        u64 maxdiag = 0;
+        for (int i = 0; i < 12; i++) {
+            const u64 cv = pos_consts[360 + i], dv = pos_consts[372 + i];
+            if (cv >> 24 || dv >> 24) small = false;
+            sum += cv;
+            if (dv > maxdiag) maxdiag = dv;
+        }
+        if (sum + maxdiag >= ((unsigned __int128)1 << 24)) small = false;
+        glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<true>(qa); });
+        if (small) {
+            std::vector<u64> generic(out, out + (size_t)GLP_PLONK_NCHAL * N);
+            glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<true, true>(qa); });
+            for (size_t k = 0; k < generic.size(); k++) if (generic[k] != out[k]) return 2;
+        }
+    } else glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_kernel<false>(qa); });
     if (flags & GLP_CIRCUIT_SHA_GATES)      // consts then has GLP_PLONK_NCONST_SHA rows
         glp_emu_launch((unsigned)((N + 63) / 64), 64, 0, [&] { glp_quotient_sha_kernel<0>(qa, n_con - GLP_SHA_GATE_CONSTRAINTS); });
     return 0;
