@@ -74,6 +74,7 @@ class DataCommitmentMapReduce:
         self.leaf_blocks, self.fan_in, self.nq, self.pw = leaf_blocks, fan_in, num_queries, pow_bits
         self.leaf_program = self.leaf_circuit = None
         self.nodes = {}                 # (level, fan-in) -> RecursionProgram
+        self.node_replicas = {}         # (level, fan-in) -> [RecursionProgram on each map prover]
         self.record_seconds = {}
 
     # ---- Map ----------------------------------------------------------------------------------------------------------------------
@@ -148,12 +149,28 @@ class DataCommitmentMapReduce:
             fan = min(self.fan_in, len(cur))
             if len(cur) % fan or fan & (fan - 1):
                 raise ValueError("the number of proofs at a level is not a multiple of a power-of-two fan-in")
-            nxt, rp = [], None
             t0 = time.perf_counter()
-            for k in range(0, len(cur), fan):
-                rp = self._node(level, cur[k:k + fan], key)
-                proof, public = rp.prove(cur[k:k + fan], self.nq, self.pw)
-                nxt.append(proof)
+            rp = self._node(level, cur[:fan], key)
+            groups = [cur[k:k + fan] for k in range(0, len(cur), fan)]
+            if len(groups) > 1 and self.map_provers:
+                # several nodes of one level: one host thread per prover, each with its own commitment of the level's (shared) recording
+                from concurrent.futures import ThreadPoolExecutor
+                if (level, fan) not in self.node_replicas:
+                    self.node_replicas[(level, fan)] = [rp.replicate(p) for p in self.map_provers]
+                workers = [rp] + self.node_replicas[(level, fan)]
+
+                def work(w):
+                    if w:
+                        self.map_provers[w - 1].bind_thread()
+                    return [(g, workers[w].prove(groups[g], self.nq, self.pw)) for g in range(w, len(groups), len(workers))]
+                with ThreadPoolExecutor(len(workers)) as ex:
+                    done = sorted((r for f in [ex.submit(work, w) for w in range(len(workers))] for r in f.result()), key=lambda t: t[0])
+                nxt, public = [pr_[0] for _, pr_ in done], done[-1][1][1]
+            else:
+                nxt = []
+                for grp in groups:
+                    proof, public = rp.prove(grp, self.nq, self.pw)
+                    nxt.append(proof)
             if timings is not None:
                 timings.append({"level": level, "nodes": len(nxt), "fan_in": fan, "rows": rp.stats["rows"],
                                 "seconds_including_first_recording": round(time.perf_counter() - t0, 4)})
@@ -227,6 +244,10 @@ class DataCommitmentMapReduce:
         return bool(self.prover.plonk_verify(root_proof, key, self.nq, self.pw, public=public))
 
     def free(self):
+        for reps in self.node_replicas.values():
+            for rp in reps:
+                rp.circuit.free()
+        self.node_replicas = {}
         for rp in self.nodes.values():
             rp.free()
         self.nodes = {}

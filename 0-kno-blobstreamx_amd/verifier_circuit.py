@@ -663,6 +663,14 @@ class RecursionProgram:
         self.stats = dict(self.program.stats)
         return self
 
+    def replicate(self, prover):
+        """the same recorded circuit committed on ANOTHER prover (ctx) of the same GPU: same key; lets several nodes of one level be proved at
+        once, one host thread per prover (the recording itself is shared)"""
+        other = object.__new__(type(self))
+        other.prover, other.consts, other.program, other.stats = prover, self.consts, self.program, self.stats
+        other.circuit = self.program.setup(prover)
+        return other
+
     def witness(self, proofs):
         inputs, ws = self.program.inputs_from_words(proofs)
         vals = self.program.evaluate(self.consts, inputs)
