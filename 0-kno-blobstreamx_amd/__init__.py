@@ -63,7 +63,7 @@ CIRCUIT_SHA_GATES = 2
 SHA_GATE_WIRES = 144
 SHA_ROW_E, SHA_ROW_A, SHA_ROW_W, SHA_ROW_ADD = 0, 1, 2, 3
 CIRCUIT_POSEIDON_GATE = 1
-POS_GATE_WIRES = 130
+POS_GATE_WIRES = 135
 
 
 class FriStatement(ctypes.Structure):

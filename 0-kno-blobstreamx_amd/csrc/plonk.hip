@@ -136,7 +136,7 @@ extern "C" int glp_plonk_setup(glp_ctx* c, uint32_t log_n, uint32_t n_wires, con
 
 extern "C" void glp_plonk_free(glp_plonk_circuit* ck) { delete ck; }
 
-// witness generation for Poseidon rows: wires 12..129 of every listed row from its wires 0..11 (plonk_gates.h)
+// witness generation for Poseidon rows: wires 12..134 of every listed row from its wires 0..11 and its swap bit (plonk_gates.h)
 extern "C" int glp_poseidon_gate_fill_rows(glp_ctx* c, uint64_t* d_wire_vals, uint32_t log_n, uint32_t n_wires, const uint32_t* d_rows,
                                            uint32_t n_rows) {
     if (!c) return GLP_E_INVALID;

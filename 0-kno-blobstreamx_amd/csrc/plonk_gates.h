@@ -9,9 +9,13 @@
 //               (c0 = c1 = 0 makes it the constant gate  w = c2)
 //   public input  row i < n_public:                            q_pi * wire_0 - PI(x) = 0,  PI = the polynomial that is
 //               public_input[i] on row i < n_public and 0 on every other row (the verifier evaluates it itself)
-//   Poseidon    a q_pos row carries one width-12 permutation:  wires 0..11 = input, 12..23 = output, 24..129 = the
-//               S-box inputs of every round after the first (3 x 12 full, 22 partial, 4 x 12 full), so that every
-//               constraint has degree 7 in the wires (8 with the selector): 118 constraints
+//   Poseidon    a q_pos row carries one width-12 permutation with an optional SWAP of its first two 4-word blocks (the Merkle
+//               path step: "is this node the right child?"):  wires 0..11 = input, 12..23 = output, 24 = swap bit s, 25..130 = the
+//               S-box inputs of every round after the first (3 x 12 full, 22 partial, 4 x 12 full), 131..134 = delta_i =
+//               s * (in[4+i] - in[i]); the permuted state is (in[0..4) + delta, in[4..8) - delta, in[8..12)).  Every
+//               constraint has degree <= 7 in the wires (8 with the selector): 123 constraints
+//                 s (s - 1)                                                                       (1)
+//                 delta_i - s (in[4+i] - in[i])                                   i = 0..3      (4)
 //                 a_r[i]  - (state before the S-box of full round r)[i]          r = 1..3      (36)
 //                 p_r     - (lane 0 before the S-box of partial round r)          r = 0..21     (22)
 //                 b_r[i]  - (state before the S-box of final full round r)[i]     r = 0..3      (48)
@@ -22,8 +26,11 @@
 #include "hash_kernels.cuh"
 
 #define GLP_PLONK_NCONST 6
-#define GLP_POS_GATE_WIRES 130
-#define GLP_POS_GATE_CONSTRAINTS 118
+#define GLP_POS_GATE_WIRES 135
+#define GLP_POS_GATE_CONSTRAINTS 123
+#define GLP_POS_SWAP_WIRE 24
+#define GLP_POS_ADVICE0 25            // first S-box-input wire
+#define GLP_POS_DELTA0 131
 #define GLP_CIRCUIT_POSEIDON_GATE 1u
 
 // ---- field policies ------------------------------------------------------------------------------------------------
@@ -65,15 +72,27 @@ GL_HD void glp_gate_mds(typename O::F (&s)[12], const u64* circ, const u64* diag
     for (int r = 0; r < 12; r++) s[r] = out[r];
 }
 
-// The 118 constraints of one Poseidon row, in order.  wire(j) -> F gives wire j of the row (j < GLP_POS_GATE_WIRES);
+// The 123 constraints of one Poseidon row, in order.  wire(j) -> F gives wire j of the row (j < GLP_POS_GATE_WIRES);
 // emit(F) receives each constraint value (zero on a correctly filled row).
 // consts: rc [30][12], circ [12], diag [12] (the arguments of glp_set_poseidon_constants).
 template <class O, class WireFn, class EmitFn>
 GL_HD void glp_poseidon_gate_constraints(WireFn&& wire, const u64* rc, const u64* circ, const u64* diag, EmitFn&& emit) {
     typedef typename O::F F;
     F s[12];
-    for (int i = 0; i < 12; i++) s[i] = O::addc(wire(i), rc[i]);          // S-box inputs of round 0: input + constants
-    int rnd = 0, aw = 24;
+    {   // the conditional swap: 5 constraints, then the state that is permuted
+        const F sw = wire(GLP_POS_SWAP_WIRE);
+        emit(O::sub(O::mul(sw, sw), sw));
+        F in[12];
+        for (int i = 0; i < 12; i++) in[i] = wire(i);
+        for (int i = 0; i < 4; i++) {
+            const F d = wire(GLP_POS_DELTA0 + i);
+            emit(O::sub(d, O::mul(sw, O::sub(in[4 + i], in[i]))));
+            in[i] = O::add(in[i], d);
+            in[4 + i] = O::sub(in[4 + i], d);
+        }
+        for (int i = 0; i < 12; i++) s[i] = O::addc(in[i], rc[i]);        // S-box inputs of round 0: state + constants
+    }
+    int rnd = 0, aw = GLP_POS_ADVICE0;
     for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
         if (r > 0) {
             for (int i = 0; i < 12; i++) { const F a = wire(aw + i); emit(O::sub(a, s[i])); s[i] = a; }
@@ -96,15 +115,23 @@ GL_HD void glp_poseidon_gate_constraints(WireFn&& wire, const u64* rc, const u64
     for (int i = 0; i < 12; i++) emit(O::sub(wire(12 + i), s[i]));
 }
 
-// Witness of one Poseidon row: given the 12 inputs, every other wire (out[0..118) = wires 12..129: output, then the
-// S-box inputs in the gate's wire order).  Base field, canonical.  The same walk as the constraints, storing instead of
-// comparing — so a row filled by this function satisfies them by construction, and the output equals
-// glp_poseidon_permute of the input (tests compare both with the oracle's permutation).
-GL_HD void glp_poseidon_gate_fill(const u64 (&in)[12], const u64* rc, const u64* circ, const u64* diag, u64 (&out)[GLP_POS_GATE_WIRES - 12]) {
+// Witness of one Poseidon row: given the 12 inputs and the swap bit, every other wire — out[j] = wire 12 + j for j < 12 (the output), out[12] is
+// wire 24 (the swap bit itself, rewritten unchanged), out[13 .. 118] the S-box inputs in the gate's wire order (wires 25..130), out[119..122] the
+// deltas (wires 131..134).  Base field, canonical.  The same walk as the constraints, storing instead of comparing — so a row filled by this function
+// satisfies them by construction (for a boolean swap bit), and with swap = 0 the output equals glp_poseidon_permute of the input.
+GL_HD void glp_poseidon_gate_fill(const u64 (&in_)[12], u64 swap, const u64* rc, const u64* circ, const u64* diag, u64 (&out)[GLP_POS_GATE_WIRES - 12]) {
     typedef GlpGateBase O;
-    u64 s[12];
+    u64 in[12], s[12];
+    for (int i = 0; i < 12; i++) in[i] = in_[i];
+    out[12] = swap;
+    for (int i = 0; i < 4; i++) {
+        const u64 d = O::mul(swap, O::sub(in[4 + i], in[i]));
+        out[GLP_POS_DELTA0 - 12 + i] = d;
+        in[i] = O::add(in[i], d);
+        in[4 + i] = O::sub(in[4 + i], d);
+    }
     for (int i = 0; i < 12; i++) s[i] = O::addc(in[i], rc[i]);
-    int rnd = 0, aw = 12;                                                     // out[] index of wire 24
+    int rnd = 0, aw = GLP_POS_ADVICE0 - 12;                                   // out[] index of wire 25
     for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
         if (r > 0) { for (int i = 0; i < 12; i++) out[aw + i] = s[i]; aw += 12; }
         for (int i = 0; i < 12; i++) s[i] = glp_gate_sbox7<O>(s[i]);

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) glp_scan_apply_kernel(const u64* __restri
 //   1            q_pi * wire_0 - PI(x)
 //   2 + 3c       prev_c * prod(num) - next_c * prod(den)            chunk c of 8 routed wires
 //   3+3c, 4+3c   the two arithmetic gates of chunk c (wires 8c..8c+3 and 8c+4..8c+7)
-//   2+3M+k       q_pos * (constraint k of the Poseidon row), k < 118     (POS circuits only)
+//   2+3M+k       q_pos * (constraint k of the Poseidon row), k < 123     (POS circuits only)
 // out[t][i] = (sum alpha_t^idx * constraint_idx) / (x^n - 1).
 struct GlpQuotientArgs {
     const u64* consts; const u64* sigmas; const u64* wires; const u64* zs; const u64* pi; const u64* ks;
@@ -181,7 +181,7 @@ struct GlpQuotientArgs {
     const u64* inv_xm1;            // [N] 1 / (x_i - 1), bit-reversed order (built once per domain)
     u64* out;                      // [NCHAL][N]
 };
-// The 118 Poseidon-row constraints in the base field with the permutation kernels' arithmetic (hash_kernels.cuh): S-boxes on arbitrary u64
+// The 123 Poseidon-row constraints in the base field with the permutation kernels' arithmetic (hash_kernels.cuh): S-boxes on arbitrary u64
 // representatives, the MDS layer on its small-integer accumulators (SMALL: every entry < 2^24 — 12 x 12 multiply-adds per round cost ~1.4 VALU each
 // instead of a full field multiplication and addition, the difference between 95k and 6k VALU per LDE point), values canonicalised only where
 // a constraint is emitted.  The same walk, in the same order, as glp_poseidon_gate_constraints<GlpGateBase> (which stays the definition: the
@@ -189,8 +189,20 @@ struct GlpQuotientArgs {
 template <bool SMALL, class WireFn, class EmitFn>
 GL_HD void glp_poseidon_gate_constraints_fast(WireFn&& wire, const u64* rc, const u64* circ, const u64* diag, EmitFn&& emit) {
     u64 s[12];
-    for (int i = 0; i < 12; i++) s[i] = gl_add(wire(i), rc[i]);
-    int rnd = 0, aw = 24;
+    {
+        const u64 sw = wire(GLP_POS_SWAP_WIRE);
+        emit(gl_sub(gl_mul(sw, sw), sw));
+        u64 in[12];
+        for (int i = 0; i < 12; i++) in[i] = wire(i);
+        for (int i = 0; i < 4; i++) {
+            const u64 d = wire(GLP_POS_DELTA0 + i);
+            emit(gl_sub(d, gl_mul(sw, gl_sub(in[4 + i], in[i]))));
+            in[i] = gl_add(in[i], d);
+            in[4 + i] = gl_sub(in[4 + i], d);
+        }
+        for (int i = 0; i < 12; i++) s[i] = gl_add(in[i], rc[i]);
+    }
+    int rnd = 0, aw = GLP_POS_ADVICE0;
     for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
         if (r > 0) {
             for (int i = 0; i < 12; i++) { const u64 v = wire(aw + i); emit(gl_sub(v, gl_canon(s[i]))); s[i] = v; }
@@ -272,7 +284,7 @@ __global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
         }
     }
     if constexpr (POS) {
-        // one Poseidon row per point: the 118 constraints, each weighted by its alpha power, then the selector once
+        // one Poseidon row per point: the 123 constraints, each weighted by its alpha power, then the selector once
         const u64 q_pos = a.consts[5 * N + i];
         u64 pacc[GLP_PLONK_NCHAL];
         for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) pacc[t] = 0;
@@ -333,7 +345,7 @@ __global__ void __launch_bounds__(64) glp_sha_gate_fill_kernel(u64* __restrict__
     for (int j = 0; j < 132; j++) wires[(u64)(12 + j) * n + row] = bits[j];
 }
 
-// ---- Poseidon-row witness: for each listed row, wires 12..129 from wires 0..11 (plonk_gates.h) ----
+// ---- Poseidon-row witness: for each listed row, wires 12..134 from wires 0..11 and the swap bit in wire 24 (plonk_gates.h) ----
 // wires: [W][n] values on the trace domain; rows: n_rows row indices; consts: rc[360], circ[12], diag[12] (device)
 template <int UNUSED = 0>
 __global__ void __launch_bounds__(64) glp_poseidon_gate_fill_kernel(u64* __restrict__ wires, u64 n, const u32* __restrict__ rows, u32 n_rows,
@@ -344,7 +356,7 @@ __global__ void __launch_bounds__(64) glp_poseidon_gate_fill_kernel(u64* __restr
     if (row >= n) return;
     u64 in[12], out[GLP_POS_GATE_WIRES - 12];
     for (int j = 0; j < 12; j++) in[j] = wires[(u64)j * n + row];
-    glp_poseidon_gate_fill(in, consts, consts + 360, consts + 372, out);
+    glp_poseidon_gate_fill(in, wires[(u64)GLP_POS_SWAP_WIRE * n + row], consts, consts + 360, consts + 372, out);
     for (int j = 0; j < GLP_POS_GATE_WIRES - 12; j++) wires[(u64)(12 + j) * n + row] = out[j];
 }
 

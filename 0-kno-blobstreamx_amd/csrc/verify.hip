@@ -618,7 +618,7 @@ extern "C" int glp_poseidon_permute_host(const uint64_t* h_rc, const uint64_t* h
 //   4 EINV   w0 w1 x0 x1        (w0,w1) = 1/(x0 + x1 X)          5 ZERO  w            w = 0
 //   6 POSEIDON o0..o11 i0..i11  outputs = permutation(inputs)
 //   7 SHA_E T1 e_new e f g h d w K    8 SHA_A a_new a b c T1    9 SHA_W w_new w16 w15 w7 w2    10 ADD32 s x y      (the SHA rows of plonk_gates.h;
-//   11 BITS w x shift bits   w = (x >> shift) mod 2^bits
+//   11 BITS w x shift bits   w = (x >> shift) mod 2^bits     12 POSEIDON_SWAP o0..o11 i0..i11 s   the Poseidon row with its swap bit
 //     an input that is not a 32-bit word -> GLP_E_REJECT with *first_bad = (size_t)-1: no witness satisfies the row)
 // eq_pairs: 2*n_eq variable indices that must hold equal values (the circuit's copy constraints between DIFFERENT variables): the first
 // violated pair is reported through *first_bad and the call returns GLP_E_REJECT — the witness does not satisfy the circuit (e.g. the
@@ -733,6 +733,18 @@ static int witness_run(const Hasher& h, const u64* prog, size_t pc, size_t end, 
                 if (!wr(a[0])) return GLP_E_INVALID;
                 values[a[0]] = (x + y) & 0xFFFFFFFFull;
                 pc += 4;
+                break;
+            }
+            case 12: {  // POSEIDON_SWAP o0..o11 | i0..i11 | s:  the permutation of the input with its first two 4-word blocks exchanged when s = 1
+                if (pc + 26 > end || !ok(a[24]) || !rd(a[24])) return GLP_E_INVALID;
+                u64 st[12];
+                for (int i = 0; i < 12; i++) { if (!ok(a[i]) || !ok(a[12 + i]) || !rd(a[12 + i])) return GLP_E_INVALID; st[i] = values[a[12 + i]]; }
+                const u64 sw = values[a[24]];
+                if (sw > 1) return GLP_E_REJECT;                       // not a bit: the row's booleanity constraint cannot hold
+                if (sw) for (int i = 0; i < 4; i++) { const u64 t = st[i]; st[i] = st[4 + i]; st[4 + i] = t; }
+                h.permute(st);
+                for (int i = 0; i < 12; i++) { if (!wr(a[i])) return GLP_E_INVALID; values[a[i]] = st[i]; }
+                pc += 26;
                 break;
             }
             case 11: {  // BITS  w | x shift bits:  w = (x >> shift) mod 2^bits

@@ -148,14 +148,25 @@ class CircuitBuilder:
     def public_input(self, v):
         self.public.append(v)
 
-    def poseidon(self, ins):
-        """one permutation row; ins: 12 variables -> 12 output variables (values from the library's own permutation)"""
+    def poseidon(self, ins, swap=None):
+        """one permutation row; ins: 12 variables -> 12 output variables (values from the library's own permutation).  swap: a variable holding
+        0 or 1 (the row constrains that) — 1 exchanges ins[0..4) and ins[4..8) before the permutation: the Merkle-path step without select gates"""
         assert len(ins) == 12
         permute = getattr(self.prover, "poseidon_permute_host", None) or self.prover.poseidon_permute      # host arithmetic: no device round trip
-        out = permute(np.array([[self.values[v] for v in ins]], dtype=np.uint64))[0]
+        vals = [self.values[v] for v in ins]
+        if swap is not None:
+            sv = self.values[swap]
+            if sv > 1:
+                raise ValueError("a Poseidon row's swap input is not a bit: the witness does not satisfy the circuit")
+            if sv:
+                vals = vals[4:8] + vals[:4] + vals[8:]
+        out = permute(np.array([vals], dtype=np.uint64))[0]
         outs = [self._new(int(v)) for v in out]
-        self.prog += (6, *outs, *ins)
-        self.pos_rows.append((list(ins), outs))
+        if swap is None:
+            self.prog += (6, *outs, *ins)
+        else:
+            self.prog += (12, *outs, *ins, swap)
+        self.pos_rows.append((list(ins), outs, swap))
         return outs
 
     # ---- SHA-256 rows: words (32-bit values) in, words out; the row's bit wires are filled on the device ------------------------------
@@ -237,13 +248,12 @@ class CircuitBuilder:
 
     def merkle_root_from_path(self, leaf_digest4, index_bits, siblings):
         """verify_merkle_proof: fold a digest up a path.  index_bits[l] (boolean variables, LSB first) says whether the node is the
-        RIGHT child at level l; siblings[l] = 4 variables.  Returns the 4 variables of the node reached (compare with a cap entry)."""
+        RIGHT child at level l; siblings[l] = 4 variables.  Returns the 4 variables of the node reached (compare with a cap entry).
+        One Poseidon row per level: the row's swap input orders (node, sibling) and constrains the bit to be boolean."""
         cur = list(leaf_digest4)
+        zero = self.constant(0)
         for b, sib in zip(index_bits, siblings):
-            self.assert_bool(b)
-            left = [self.select(b, s, c) for c, s in zip(cur, sib)]
-            right = [self.select(b, c, s) for c, s in zip(cur, sib)]
-            cur = self.two_to_one(left, right)
+            cur = self.poseidon(cur + list(sib) + [zero] * 4, swap=b)[:4]
         return cur
 
     # ---- layout ---------------------------------------------------------------------------------------------------------------
@@ -281,12 +291,14 @@ class WitnessProgram:
             cj.append(0); ci.append(i); cv.append(v)
             i += 1
         self.pos_row_ids = []
-        for ins, outs in b.pos_rows:
+        for ins, outs, swap in b.pos_rows:
             consts[5, i] = 1
             for j, v in enumerate(ins):
                 cj.append(j); ci.append(i); cv.append(v)
             for j, v in enumerate(outs):
                 cj.append(12 + j); ci.append(i); cv.append(v)
+            if swap is not None:
+                cj.append(24); ci.append(i); cv.append(swap)            # GLP_POS_SWAP_WIRE (an unused swap cell stays 0)
             self.pos_row_ids.append(i)
             i += 1
         sha_ids, sha_kinds = [], []
@@ -426,7 +438,8 @@ class WitnessProgram:
                                         self.eq_pairs.ctypes.data if self.eq_pairs.size else None, self.eq_pairs.size // 2, ctypes.byref(bad),
                                         sb.ctypes.data if sb is not None else None, sb.size - 1 if sb is not None else 0, nt)
         if rcode == -7:
-            what = "a SHA row input is not a 32-bit word" if bad.value == ctypes.c_size_t(-1).value else f"copy constraint {bad.value} fails"
+            what = ("a row input is out of range (a SHA word above 32 bits, a swap bit above 1)" if bad.value == ctypes.c_size_t(-1).value
+                    else f"copy constraint {bad.value} fails")
             raise ValueError(f"the inputs do not satisfy the circuit ({what})")
         if rcode != 0:
             raise ValueError("witness program or inputs malformed")

@@ -12,7 +12,7 @@ verify_proof``, ``fri::recursive_verifier``, ``iop::challenger::RecursiveChallen
     bits choosing sides, cap entry chosen by the remaining bits); the batch combination sum alpha^k (f_k(x) - y_k)/(x - z_p) in the
     quadratic extension; every fold layer (the layer value continues the fold, arity-2^a folding with beta, beta^2, ...); the final polynomial;
   * the PLONK identity at zeta (L_1, public inputs, permutation argument chunks, arithmetic gates, and — for a child that is itself a
-    Poseidon-row circuit, e.g. a recursion proof — the 118 Poseidon-row constraints) against the quotient chunks.
+    Poseidon-row circuit, e.g. a recursion proof — the 123 Poseidon-row constraints) against the quotient chunks.
 Bound as constants of the verifier circuit: the shape (header words, FRI parameters) and the leaf circuit's verifying key.  Returned: the
 variables of the child's public inputs and of its 4-word digest, for the caller to expose or constrain.
 
@@ -174,7 +174,7 @@ class _Challenger:
 
 
 def _poseidon_row_constraints(g, wires, consts):
-    """the 118 constraint values of a Poseidon row (csrc/plonk_gates.h) on extension-field wire values: the same walk as the gate, S-boxes
+    """the 123 constraint values of a Poseidon row (csrc/plonk_gates.h; swap bit in wire 24, deltas in 131..134) on extension-field wire values: the same walk as the gate, S-boxes
     as extension products, an MDS term as one arithmetic gate per component (acc + const * x)"""
     rc, circ, diag = consts
     kc = [g.k(c) for c in circ]
@@ -196,8 +196,15 @@ def _poseidon_row_constraints(g, wires, consts):
             out.append((g.lin(1, acc[0], rc_next[r]), acc[1]) if rc_next is not None else acc)
         return out
 
-    s = [(g.lin(1, wires[i][0], rc[i]), wires[i][1]) for i in range(12)]
-    out, rnd, aw = [], 0, 24
+    sw = wires[24]
+    out = [g.e_sub(g.e_mul(sw, sw), sw)]
+    st = list(wires[:12])
+    for i in range(4):                                                     # delta_i = s * (in[4+i] - in[i]); the permuted state swaps by it
+        d = wires[131 + i]
+        out.append(g.e_sub(d, g.e_mul(sw, g.e_sub(st[4 + i], st[i]))))
+        st[i], st[4 + i] = g.e_add(st[i], d), g.e_sub(st[4 + i], d)
+    s = [(g.lin(1, st[i][0], rc[i]), st[i][1]) for i in range(12)]
+    rnd, aw = 0, 25
     for r in range(4):
         if r > 0:
             out += [g.e_sub(wires[aw + i], s[i]) for i in range(12)]
@@ -218,7 +225,7 @@ def _poseidon_row_constraints(g, wires, consts):
         aw += 12
         rnd += 1
     out += [g.e_sub(wires[12 + i], s[i]) for i in range(12)]
-    assert len(out) == 118 and aw == 130
+    assert len(out) == 123 and aw == 131
     return out
 
 
@@ -282,7 +289,7 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
                       proof_id=0, sha=False):
     """lay the whole verification of `proof` down on builder `b` (see the module docstring).  The expected statement shape and the leaf
     circuit's key are CONSTANTS of the resulting circuit.  poseidon_consts = (rc, circ, diag): the child is a Poseidon-row circuit (flags = 1,
-    e.g. a proof made by this very function's circuit: recursion on recursion); its 118 row constraints are then part of the identity.
+    e.g. a proof made by this very function's circuit: recursion on recursion); its 123 row constraints are then part of the identity.
     sha: the child has SHA-256 rows (flag 2, ten constant columns): the 140 constraints of that block join the identity too.
     Returns {"public": [vars], "digest": [4 vars]}."""
     import numpy as np
@@ -419,14 +426,37 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     ch.observe(nonce)
     idx_bits = [g.bits_canonical(ch.challenge())[:log_N] for _ in range(num_queries)]
 
+    minterm_cache = {}
+
+    def minterms(sel_bits):
+        """one-hot indicators of the index spelled by sel_bits (LSB first): m[e] = prod_k (bit_k if e has bit k else 1 - bit_k).  Shared by
+        every tree opened at the same query index (the four initial trees select the same cap entry)."""
+        key = tuple(sel_bits)
+        if key not in minterm_cache:
+            m = [g.one]
+            for k, bit in enumerate(sel_bits):
+                nb = g.lin(P - 1, bit, 1)                                  # 1 - bit
+                if k == 0:
+                    m = [nb, bit]
+                else:
+                    m = [g.mul(x, nb) for x in m] + [g.mul(x, bit) for x in m]
+            minterm_cache[key] = m
+        return minterm_cache[key]
+
     def merkle_to_cap(leaf_vars, bits, path_vars, cap_vars, cap_log):
         plen = len(path_vars)
         top = b.merkle_root_from_path(b.hash_no_pad(leaf_vars), bits[:plen], path_vars)
-        entries = [cap_vars[4 * e: 4 * e + 4] for e in range(1 << cap_log)]
-        for k in range(cap_log):
-            bit = bits[plen + k]
-            entries = [[g.select(bit, hi, lo) for lo, hi in zip(entries[2 * e], entries[2 * e + 1])] for e in range(len(entries) // 2)]
-        for x, y in zip(top, entries[0]):
+        if cap_log == 0:
+            entry = cap_vars[:4]
+        else:
+            m = minterms(bits[plen:plen + cap_log])
+            entry = []
+            for w in range(4):                                             # word w of the selected entry = sum_e m[e] * cap[e][w]
+                acc = g.mul(m[0], cap_vars[w])
+                for e in range(1, 1 << cap_log):
+                    acc = b.arith(1, 1, 0, m[e], cap_vars[4 * e + w], acc)
+                entry.append(acc)
+        for x, y in zip(top, entry):
             b.assert_equal(x, y)
 
     def point_from_bits(bits, nbits, shift):

@@ -183,15 +183,16 @@ void glp_free_host(void* p);
  * Gates:
  *   arithmetic / constant   every group of 4 routed wires (x, y, z, w):  q_arith * (c0*x*y + c1*z + c2 - w) = 0
  *   public input            q_pi * wire_0 - PI(x) = 0: set q_pi = 1 on rows 0..n_public-1 — wire 0 of row i is public input i
- *   Poseidon (flag)         a q_pos row carries one permutation with the ctx's constants: wires 0..11 in, 12..23 out,
- *                           24..129 the S-box inputs of the later rounds (118 degree-7 constraints; fill them with
+ *   Poseidon (flag)         a q_pos row carries one permutation with the ctx's constants: wires 0..11 in, 12..23 out, 24 a swap bit s
+ *                           (s = 1 exchanges in[0..4) and in[4..8) before the permutation: the Merkle-path step), 25..130 the S-box inputs of
+ *                           the later rounds, 131..134 s * (in[4+i] - in[i]) (123 constraints of degree <= 7; fill wires 12..134 with
  *                           glp_poseidon_gate_fill_rows); set q_arith = 0 on such rows
  * d_const_vals: [6][n] row values; d_sigma_vals: [n_routed][n] with sigma_j(row i) = k_{j'} * w_n^{i'} for the cell (j', i')
  * that (j, i) maps to, k_j = 7^j.  rate_bits must be 3: the quotient has degree < 8n (permutation constraint degree 9,
  * Poseidon row degree 8), so 8 chunks on the 8n-point coset is exactly what fits; it is not a tunable. */
 #define GLP_PLONK_NCONST 6
 #define GLP_CIRCUIT_POSEIDON_GATE 1u
-#define GLP_POS_GATE_WIRES 130
+#define GLP_POS_GATE_WIRES 135
 /*   SHA-256 rows (flag)     four more constant columns select the row kind — [6] q_she [7] q_sha [8] q_shw [9] q_add, so d_const_vals is
  *                           [GLP_PLONK_NCONST_SHA][n] for such a circuit — and one compression is 64 E rows (e-half of a round: T1 and the new e;
  *                           K_t in the row's c2), 64 A rows (the new a), 48 W rows (message schedule) and 2 ADD rows (the feed-forward; four
@@ -230,8 +231,8 @@ int glp_plonk_prove_ex(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wi
                        uint32_t pow_bits, uint8_t** proof, size_t* proof_len);
 int glp_plonk_prove(glp_ctx* ctx, glp_plonk_circuit* ck, const uint64_t* d_wire_vals, uint32_t num_queries, uint32_t pow_bits,
                     uint8_t** proof, size_t* proof_len);
-/* witness generation for Poseidon rows: for each of the n_rows row indices in d_rows (device, u32), wires 12..129 of that row
- * are computed from its wires 0..11, in place in d_wire_vals [n_wires][2^log_n].  Stream-ordered. */
+/* witness generation for Poseidon rows: for each of the n_rows row indices in d_rows (device, u32), wires 12..23 and 25..134 of that row
+ * are computed from its wires 0..11 and its swap bit (wire 24), in place in d_wire_vals [n_wires][2^log_n].  Stream-ordered. */
 int glp_poseidon_gate_fill_rows(glp_ctx* ctx, uint64_t* d_wire_vals, uint32_t log_n, uint32_t n_wires, const uint32_t* d_rows,
                                 uint32_t n_rows);
 /* witness generation for SHA rows: for row d_rows[k] of kind d_kinds[k] (GLP_SHA_ROW_*; both device, u32) the bit wires 12..143 are computed

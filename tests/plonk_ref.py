@@ -13,8 +13,9 @@ NCHAL = 2
 NCONST = 6                     # q_arith, c0, c1, c2, q_pi, q_pos
 TAG = 0x32304B4C504C4747       # "GGLPLK02"
 FLAG_POSEIDON = 1
-POS_WIRES = 130
-POS_CONSTRAINTS = 118
+POS_WIRES = 135
+POS_CONSTRAINTS = 123
+POS_SWAP, POS_ADV0, POS_DELTA0 = 24, 25, 131
 FLAG_SHA = 2
 NCONST_SHA = 10                # ... + q_she, q_sha, q_shw, q_add
 SHA_WIRES = 144
@@ -74,12 +75,18 @@ def _sbox(F, x):
     return F.mul(x3, x4)
 
 
-def poseidon_row(inputs, consts):
-    """the 130 wire values of a Poseidon row from its 12 inputs: in, out, then the S-box inputs of every round after the
-    first (3 x 12 full, 22 partial lane-0 values, 4 x 12 full).  consts = (rc[360], circ[12], diag[12]) as ints."""
+def poseidon_row(inputs, consts, swap=0):
+    """the 135 wire values of a Poseidon row from its 12 inputs and swap bit: in, out, swap, then the S-box inputs of every round after the
+    first (3 x 12 full, 22 partial lane-0 values, 4 x 12 full), then the 4 deltas swap * (in[4+i] - in[i]).  swap = 1 exchanges in[0..4) and
+    in[4..8) before the permutation.  consts = (rc[360], circ[12], diag[12]) as ints."""
     rc, circ, diag = consts
     F = Base
-    s = [F.addc(inputs[i], rc[i]) for i in range(12)]
+    deltas = [swap * (inputs[4 + i] - inputs[i]) % P for i in range(4)]
+    st = list(inputs)
+    for i in range(4):
+        st[i] = (st[i] + deltas[i]) % P
+        st[4 + i] = (st[4 + i] - deltas[i]) % P
+    s = [F.addc(st[i], rc[i]) for i in range(12)]
     adv = []
     rnd = 0
     for r in range(4):
@@ -98,15 +105,21 @@ def poseidon_row(inputs, consts):
         s = [_sbox(F, v) for v in s]
         s = _mds(F, s, circ, diag, rc[(rnd + 1) * 12:(rnd + 2) * 12] if rnd + 1 < 30 else None)
         rnd += 1
-    return list(inputs) + s + adv
+    return list(inputs) + s + [swap] + adv + deltas
 
 
 def poseidon_constraints(F, wires, consts):
-    """the 118 constraint values of a Poseidon row at one point; wires = the row's first 130 wire values (F elements)"""
+    """the 123 constraint values of a Poseidon row at one point; wires = the row's first 135 wire values (F elements)"""
     rc, circ, diag = consts
-    s = [F.addc(wires[i], rc[i]) for i in range(12)]
-    out = []
-    rnd, aw = 0, 24
+    sw = wires[POS_SWAP]
+    out = [F.sub(F.mul(sw, sw), sw)]
+    st = list(wires[:12])
+    for i in range(4):
+        d = wires[POS_DELTA0 + i]
+        out.append(F.sub(d, F.mul(sw, F.sub(st[4 + i], st[i]))))
+        st[i], st[4 + i] = F.add(st[i], d), F.sub(st[4 + i], d)
+    s = [F.addc(st[i], rc[i]) for i in range(12)]
+    rnd, aw = 0, POS_ADV0
     for r in range(4):
         if r > 0:
             for i in range(12):
@@ -132,7 +145,7 @@ def poseidon_constraints(F, wires, consts):
         rnd += 1
     for i in range(12):
         out.append(F.sub(wires[12 + i], s[i]))
-    assert len(out) == POS_CONSTRAINTS and aw == POS_WIRES
+    assert len(out) == POS_CONSTRAINTS and aw == POS_DELTA0
     return out
 
 
@@ -295,7 +308,7 @@ def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, posei
         if i in pos:
             for j in range(12):
                 fresh_or_copy(j, i)                       # inputs: free cells (copies of earlier outputs chain permutations)
-            row = poseidon_row([wires[j][i] for j in range(12)], consts)
+            row = poseidon_row([wires[j][i] for j in range(12)], consts, swap=int(rng.integers(0, 2)))
             for j in range(12, POS_WIRES):
                 wires[j][i] = row[j]
                 if j < R:

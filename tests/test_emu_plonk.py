@@ -104,7 +104,7 @@ def test_quotient_on_lde_domain(emu, oracle, log_n, W):
 
 def test_poseidon_row_is_the_permutation(emu, oracle):
     """the Poseidon row's witness: the Python restatement, the product's fill kernel (emulated) and the oracle's permutation agree,
-    and a filled row satisfies all 118 constraints while a corrupted one does not"""
+    and a filled row satisfies all 123 constraints (swap bit 0 and 1) while a corrupted one does not"""
     consts = poseidon_consts("small")
     oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
     ic = pr.int_consts(consts)
@@ -115,6 +115,7 @@ def test_poseidon_row_is_the_permutation(emu, oracle):
     wires[:12, 0] = 0
     wires[:12, 1] = P - 1
     rows = np.array([0, 1, 3, 6], dtype=np.uint32)
+    wires[pr.POS_SWAP, rows] = [0, 1, 1, 0]                      # the swap bit is an INPUT of the row (a routed cell): rows 1 and 3 swap
     before = wires.copy()
     flat = np.concatenate([np.array(a, dtype=np.uint64) for a in consts])
     assert emu.emu_poseidon_gate_fill_rows(ptr(wires), log_n, rows.ctypes.data, len(rows), ptr(flat)) == 0
@@ -122,17 +123,25 @@ def test_poseidon_row_is_the_permutation(emu, oracle):
         if r not in rows:
             assert np.array_equal(wires[:, r], before[:, r])
             continue
-        row = pr.poseidon_row([int(v) for v in before[:12, r]], ic)
+        swap = int(before[pr.POS_SWAP, r])
+        row = pr.poseidon_row([int(v) for v in before[:12, r]], ic, swap=swap)
         assert [int(v) for v in wires[:pr.POS_WIRES, r]] == row
         st = before[:12, r].copy()
+        if swap:
+            st[:4], st[4:8] = before[4:8, r], before[:4, r]
         oracle.orc_poseidon_permute(ptr(st))
         assert [int(v) for v in st] == row[12:24]
         assert not any(pr.poseidon_constraints(pr.Base, row, ic))
         assert np.array_equal(wires[pr.POS_WIRES:, r], before[pr.POS_WIRES:, r])
-        for j in (0, 12, 24, 60, 61, 82, 129):
+        for j in (0, 5, 12, 24, 25, 60, 61, 82, 130, 131, 134):
+            if j == 24 and r < 2:
+                continue                                         # rows 0 and 1 have equal input halves: either swap bit satisfies them
             bad = list(row)
             bad[j] = (bad[j] + 1) % P
             assert any(pr.poseidon_constraints(pr.Base, bad, ic)), f"wire {j} is not constrained"
+    # a swap "bit" that is not a bit cannot satisfy the row
+    row2 = pr.poseidon_row([int(v) for v in before[:12, 3]], ic, swap=2)
+    assert any(pr.poseidon_constraints(pr.Base, row2, ic))
 
 
 @pytest.mark.parametrize("log_n,W,R,n_public,pos_rows", [(3, 16, 8, 2, ()), (4, 24, 16, 5, ()), (3, 136, 80, 3, (1, 4, 5)), (4, 136, 24, 0, (0, 15))])

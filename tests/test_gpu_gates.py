@@ -89,6 +89,9 @@ def test_poseidon_gate_circuit(setup, pkg, log_n, W, R, n_public, n_pos):
     wires = circ["wires"]
     # (1) wire values = the permutation, three ways
     states = np.ascontiguousarray(wires[:12, rows].T)
+    swapped = wires[pref.POS_SWAP, rows] == 1                   # rows whose swap bit is set permute (in[4..8), in[0..4), in[8..12))
+    states[swapped] = states[swapped][:, [4, 5, 6, 7, 0, 1, 2, 3, 8, 9, 10, 11]]
+    assert swapped.any() and not swapped.all()
     got = prover.poseidon_permute(states)
     assert np.array_equal(got, wires[12:24, rows].T)
     for k in (0, len(rows) // 2, len(rows) - 1):
@@ -97,7 +100,8 @@ def test_poseidon_gate_circuit(setup, pkg, log_n, W, R, n_public, n_pos):
         assert np.array_equal(st, wires[12:24, rows[k]])
     # (2) the GPU witness filler: blank wires 12..129 of the Poseidon rows, refill on the device
     blank = wires.copy()
-    blank[12:pref.POS_WIRES, rows] = 0
+    blank[12:pref.POS_SWAP, rows] = 0                           # everything the filler derives: not the inputs, not the swap bit (wire 24)
+    blank[pref.POS_SWAP + 1:pref.POS_WIRES, rows] = 0
     dw = prover.to_device(blank)
     prover.poseidon_gate_fill_rows(dw, log_n, W, rows)
     assert np.array_equal(dw.download(wires.shape), wires)
