@@ -469,14 +469,23 @@ class WitnessProgram:
 
     def check_words(self, vals, ws):
         """the recorded facts that tie non-input words to computed variables (redundant copies inside a proof, query indices)"""
-        for k, pos, var in self.wc_var:
-            if int(ws[k][pos]) != int(vals[var]):
-                raise ValueError(f"input {k}: word {pos} differs from the value the circuit derives")
-        o = 0
-        for k, pos, nb in self.wc_bits:
-            if int(ws[k][pos]) != sum(int(b) << j for j, b in enumerate(vals[self.wc_bit_vars[o:o + nb]])):
-                raise ValueError(f"input {k}: word {pos} differs from the index the transcript derives")
-            o += nb
+        sizes = np.array([w.size for w in ws], dtype=np.int64)
+        off = np.concatenate(([0], np.cumsum(sizes)))[:-1]
+        flat = np.concatenate(ws) if ws else np.zeros(0, dtype=np.uint64)
+        vals = np.asarray(vals, dtype=np.uint64)
+        if self.wc_var.shape[0]:
+            k, pos, var = self.wc_var[:, 0], self.wc_var[:, 1], self.wc_var[:, 2]
+            bad = np.nonzero(flat[off[k] + pos] != vals[var])[0]
+            if bad.size:
+                raise ValueError(f"input {int(k[bad[0]])}: word {int(pos[bad[0]])} differs from the value the circuit derives")
+        if self.wc_bits.shape[0]:
+            k, pos, nb = self.wc_bits[:, 0], self.wc_bits[:, 1], self.wc_bits[:, 2]
+            starts = np.concatenate(([0], np.cumsum(nb)))[:-1]
+            shifts = (np.arange(self.wc_bit_vars.size) - np.repeat(starts, nb)).astype(np.uint64)
+            packed = np.add.reduceat(vals[self.wc_bit_vars] << shifts, starts)         # bit counts are >= 1 and <= 64, values are 0/1
+            bad = np.nonzero(flat[off[k] + pos] != packed)[0]
+            if bad.size:
+                raise ValueError(f"input {int(k[bad[0]])}: word {int(pos[bad[0]])} differs from the index the transcript derives")
 
     def device_witness(self, prover, vals):
         """variable values -> wire matrix on the device: the values are uploaded (8 bytes per VARIABLE, not per cell) and placed by the resident
