@@ -166,7 +166,7 @@ class Sha256Rows:
     def __init__(self, builder):
         self.b = builder
         self.zero = builder.constant(0)
-        self.c2_8, self.c2_24 = builder.constant(1 << 8), builder.constant(1 << 24)
+        self.c2_8, self.c2_24, self.c2_32 = builder.constant(1 << 8), builder.constant(1 << 24), builder.constant(1 << 32)
         self.one = builder.constant(1)
 
     def word(self, v):
@@ -218,6 +218,127 @@ class Sha256Rows:
         for off in (0, 16):
             state = self.compress(state, msg[off:off + 16])
         return state
+
+
+    # ---- byte strings ---------------------------------------------------------------------------------------------------------------
+    def byte(self, v):
+        """range-check a variable as a byte: v < 2^32 and v * 2^24 < 2^32 as integers (v * 2^24 < 2^56 cannot wrap)"""
+        b = self.b
+        b.range32(v)
+        b.range32(b.arith(1, 0, 0, v, self.c2_24, v))
+        return v
+
+    def word_from_bytes(self, b4):
+        """big-endian word of four range-checked bytes (constants allowed)"""
+        b = self.b
+        c16, c8 = b.constant(1 << 16), self.c2_8
+        hi = b.arith(1, 1, 0, b4[0], self.c2_24, b.arith(1, 0, 0, b4[1], c16, b4[1]))      # b0 * 2^24 + b1 * 2^16
+        return b.arith(1, 1, 0, b4[2], c8, b.arith(1, 1, 0, hi, self.one, b4[3]))           # b2 * 2^8 + (hi + b3)
+
+    def hash_bytes(self, byte_vars):
+        """SHA-256 of a message given as range-checked byte variables (any length, fixed at circuit-build time): FIPS 180-4 padding as
+        constants, one compression per 64-byte block.  Returns the 8 digest words."""
+        b = self.b
+        n = len(byte_vars)
+        pad = [b.constant(0x80)] + [self.zero] * ((55 - n) % 64) + [b.constant(v) for v in (8 * n).to_bytes(8, "big")]
+        msg = list(byte_vars) + pad
+        assert len(msg) % 64 == 0
+        words = [self.word_from_bytes(msg[k:k + 4]) for k in range(0, len(msg), 4)]
+        state = [b.constant(v) for v in IV256]
+        for off in range(0, len(words), 16):
+            state = self.compress(state, words[off:off + 16])
+        return state
+
+    def bytes_of_word(self, w):
+        """the four big-endian bytes of a range-checked word, as range-checked byte variables"""
+        b = self.b
+        bs = [b.bit_field(w, 24 - 8 * k, 8) for k in range(4)]
+        for v in bs:
+            self.byte(v)
+        b.assert_equal(self.word_from_bytes(bs), w)
+        return bs
+
+
+def validator_set_statement(b, g, pubkeys, voting_powers, signed, numerator=2, denominator=3):
+    """Lay down, on builder b (gadget g = Sha256Rows(b)), the non-cryptographic half of a Tendermint commit check ([RECALLED] tendermintx's
+    validator-set and voting-power logic; the encodings are [SPEC] protobuf / RFC 6962, as in blobstream.py):
+      * every validator's Merkle leaf 0x00 || SimpleValidator{pub_key{ed25519 = pubkey}, voting_power} is hashed in-circuit from its 32 key bytes
+        and its power's varint groups (7 bits each; the number of groups is a constant of the circuit, like the number of validators);
+      * the RFC 6962 tree over the leaves (split at the largest power of two below n) gives validators_hash;
+      * signed_power = sum of the powers whose `signed` flag is 1, total_power = the sum of all, and
+        denominator * signed_power > numerator * total_power  (a 60-bit non-negative difference, shown by range checks).
+    The flags are boolean WITNESSES: that a flagged validator's Ed25519 signature verifies is NOT constrained here (the GPU witness kernel checks it
+    outside the circuit; the curve arithmetic in-circuit is what upstream's STARK is for).  Powers must be below 2^49 (7 varint groups), so no sum can
+    wrap.  Returns (validators_hash: 8 word variables, signed_power, total_power)."""
+    n = len(pubkeys)
+    assert n >= 1 and len(voting_powers) == n and len(signed) == n
+    c128 = b.constant(128)
+    leaves, powers, flags = [], [], []
+    for key, power, sg in zip(pubkeys, voting_powers, signed):
+        power = int(power)
+        if not 0 < power < (1 << 49) or len(key) != 32:
+            raise ValueError("validator: 32-byte key and 0 < voting power < 2^49 expected")
+        kb = [g.byte(b.var(v)) for v in bytes(key)]
+        groups = []
+        p = power
+        while True:
+            groups.append(p & 0x7F)
+            p >>= 7
+            if not p:
+                break
+        gv = []
+        for gval in groups:
+            v = b.var(gval)
+            b.range32(v)
+            b.range32(b.arith(1, 0, 0, v, b.constant(1 << 25), v))                       # v < 2^7
+            gv.append(v)
+        pw = gv[-1]
+        for v in reversed(gv[:-1]):
+            pw = b.arith(1, 1, 0, pw, c128, v)                                            # Horner: power = sum g_j * 128^j
+        vbytes = [b.arith(0, 1, 0x80, v, v, v) for v in gv[:-1]] + [gv[-1]]               # continuation bit on all but the last group
+        leaf = [b.constant(v) for v in (0x00, 0x0a, 0x22, 0x0a, 0x20)] + kb + [b.constant(0x10)] + vbytes
+        leaves.append(g.hash_bytes(leaf))
+        powers.append(pw)
+        f = b.var(1 if sg else 0)
+        b.assert_bool(f)
+        flags.append(f)
+
+    def tree(nodes):
+        if len(nodes) == 1:
+            return nodes[0]
+        k = 1 << ((len(nodes) - 1).bit_length() - 1)                                      # largest power of two strictly below len
+        return g.hash_prefixed_64(0x01, tree(nodes[:k]) + tree(nodes[k:]))
+    root = tree(leaves)
+    total, got = powers[0], b.mul(flags[0], powers[0])
+    for pw, f in zip(powers[1:], flags[1:]):
+        total = b.add(total, pw)
+        got = b.arith(1, 1, 0, f, pw, got)
+    # d = denominator * signed - numerator * total - 1 >= 0, d < 2^60:  d = hi * 2^32 + lo with lo < 2^32, hi < 2^28
+    d = b.arith(0, denominator, P - 1, got, got, got)
+    d = b.arith(1, 1, 0, total, b.constant(P - numerator), d)
+    lo, hi = b.bit_field(d, 0, 32), b.bit_field(d, 32, 28)
+    b.range32(lo)
+    b.range32(hi)
+    b.range32(b.arith(1, 0, 0, hi, b.constant(1 << 4), hi))
+    b.assert_equal(b.arith(1, 1, 0, hi, g.c2_32, lo), d)
+    return root, got, total
+
+
+def validator_set_circuit(prover, pubkeys, voting_powers, signed, numerator=2, denominator=3):
+    """the circuit of validator_set_statement with public inputs = the 8 words of validators_hash, then signed_power and total_power.
+    Returns (circuit, device wires, public values, validators_hash bytes).  ValueError when the flagged validators do not hold more than
+    numerator/denominator of the power (the witness cannot satisfy the circuit)."""
+    from . import SHA_GATE_WIRES
+    b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
+    g = Sha256Rows(b)
+    root, got, total = validator_set_statement(b, g, pubkeys, voting_powers, signed, numerator, denominator)
+    for w in root:
+        b.public_input(w)
+    b.public_input(got)
+    b.public_input(total)
+    digest = b"".join(struct.pack(">I", b.value(w)) for w in root)
+    ck, dw, public = b.build()
+    return ck, dw, public, digest
 
 
 def data_commitment_rows_circuit(prover, heights, data_roots):

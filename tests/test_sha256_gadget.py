@@ -123,6 +123,124 @@ def test_sha_rows_gadget_matches_hashlib_and_replays():
         prog.evaluate(consts, [1 << 32] + inp[1:])
 
 
+@pytest.mark.parametrize("length", [0, 1, 3, 55, 56, 64, 119, 130])
+def test_sha_rows_hash_bytes_matches_hashlib(length):
+    """hash_bytes: a message of range-checked byte variables of any length (padding as constants); the recorded program hashes other
+    messages of that length, and a "byte" of 256 is refused (its range check cannot hold)"""
+    gd, rec, _ = _mods()
+    consts = poseidon_consts("small")
+    rng = np.random.default_rng(length)
+    msg = rng.integers(0, 256, length, dtype=np.uint8).tobytes()
+    b = rec.CircuitBuilder(object(), n_wires=144)
+    g = gd.Sha256Rows(b)
+    digest = g.hash_bytes([g.byte(b.var(v)) for v in msg])
+    assert b"".join(struct.pack(">I", b.value(w)) for w in digest) == hashlib.sha256(msg).digest()
+    prog = b.program()
+    assert prog.stats["sha_rows"] >= 178 * ((length + 8) // 64 + 1)
+    if length:
+        m2 = rng.integers(0, 256, length, dtype=np.uint8).tobytes()
+        vals = prog.evaluate(consts, list(m2))
+        assert b"".join(struct.pack(">I", int(vals[w])) for w in digest) == hashlib.sha256(m2).digest()
+        with pytest.raises(ValueError):
+            prog.evaluate(consts, [256] + list(m2[1:]))
+        # bytes_of_word round trip on the digest words
+        bs = [x for w in digest for x in g.bytes_of_word(w)]
+        assert bytes(b.value(x) for x in bs) == hashlib.sha256(msg).digest()
+
+
+def _validators(rng, n):
+    keys = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n)]
+    powers = [int(rng.integers(1, 1 << int(rng.integers(1, 49)))) for _ in range(n)]
+    return keys, powers
+
+
+def _validators_hash(bs, keys, powers):
+    def tree(nodes):
+        if len(nodes) == 1:
+            return nodes[0]
+        k = 1 << ((len(nodes) - 1).bit_length() - 1)
+        return hashlib.sha256(b"\x01" + tree(nodes[:k]) + tree(nodes[k:])).digest()
+    return tree([hashlib.sha256(b"\x00" + bs.encode_validator(k, p)).digest() for k, p in zip(keys, powers)])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_validator_set_statement_on_the_builder(n):
+    """the validator-set hash (variable-length protobuf leaves, RFC 6962 tree with a non-power-of-two split) and the > 2/3 voting-power rule laid
+    down on the builder: the hash equals the hashlib restatement, the recorded program replays for another set of the same shape, and a
+    signer set below the threshold cannot be laid down"""
+    gd, rec, bs = _mods()
+    consts = poseidon_consts("small")
+    rng = np.random.default_rng(100 + n)
+    keys, powers = _validators(rng, n)
+    order = np.argsort(powers)[::-1]
+    signed = [False] * n
+    acc = 0
+    for i in order:                                                     # the largest holders sign until > 2/3 is reached
+        signed[i] = True
+        acc += powers[i]
+        if 3 * acc > 2 * sum(powers):
+            break
+    b = rec.CircuitBuilder(object(), n_wires=144)
+    g = gd.Sha256Rows(b)
+    root, got, total = gd.validator_set_statement(b, g, keys, powers, signed)
+    assert b"".join(struct.pack(">I", b.value(w)) for w in root) == _validators_hash(bs, keys, powers)
+    assert b.value(got) == acc and b.value(total) == sum(powers)
+    prog = b.program()
+    # replay: same shape (same varint lengths), other keys, flags unchanged
+    keys2 = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n)]
+    inputs = []
+    for k2, p, sg in zip(keys2, powers, signed):
+        groups = []
+        while True:
+            groups.append(p & 0x7F)
+            p >>= 7
+            if not p:
+                break
+        inputs += list(k2) + groups + [1 if sg else 0]
+    vals = prog.evaluate(consts, inputs)
+    assert b"".join(struct.pack(">I", int(vals[w])) for w in root) == _validators_hash(bs, keys2, powers)
+    if n > 1:
+        weak = [False] * n
+        weak[int(order[-1])] = True                                     # only the smallest holder signs
+        if 3 * powers[int(order[-1])] <= 2 * sum(powers):
+            b3 = rec.CircuitBuilder(object(), n_wires=144)
+            with pytest.raises(ValueError, match="assert_equal"):
+                gd.validator_set_statement(b3, gd.Sha256Rows(b3), keys, powers, weak)
+            # ... and the recorded program refuses those flags too (the range check of the difference fails)
+            bad_inputs = list(inputs)
+            pos = 0
+            for i, p in enumerate(powers):
+                ng = max(1, (p.bit_length() + 6) // 7)
+                bad_inputs[pos + 32 + ng] = 1 if weak[i] else 0
+                pos += 32 + ng + 1
+            with pytest.raises(ValueError):
+                prog.evaluate(consts, bad_inputs)
+
+
+@pytest.mark.gpu
+def test_validator_set_circuit_proves(prover, oracle, pkg):
+    gd, rec, bs = _mods()
+    rc, circ, diag = poseidon_consts("small")
+    prover.set_poseidon_constants(rc, circ, diag)
+    oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
+    rng = np.random.default_rng(321)
+    keys, powers = _validators(rng, 6)
+    signed = [True, True, True, True, True, False]
+    if 3 * sum(p for p, s_ in zip(powers, signed) if s_) <= 2 * sum(powers):
+        signed = [True] * 6
+    ck, dw, public, digest = gd.validator_set_circuit(prover, keys, powers, signed)
+    assert digest == _validators_hash(bs, keys, powers) == bs.validator_set_hash(prover, keys, powers)        # = the GPU witness kernel's
+    assert public[:8] == list(struct.unpack(">8I", digest)) and public[9] == sum(powers)
+    proof = ck.prove_(dw, 10, 6, public=public)
+    assert ck.verify(proof, 10, 6, public=public), prover.last_reject
+    pref.verify_plonk(proof, oracle, pos_consts=(rc, circ, diag), public=public)
+    other = list(public)
+    other[8] += 1                                                       # another signed power: another statement
+    assert not ck.verify(proof, 10, 6, public=other)
+    dw.free()
+    ck.free()
+
+
 @pytest.mark.gpu
 def test_data_commitment_on_sha_rows(prover, oracle, pkg):
     """the DataCommitment statement on the SHA row gates: same public inputs and root as the bit-decomposition circuit, 2^12 rows instead
