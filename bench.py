@@ -622,6 +622,40 @@ def data_commitment_leg(pkg, n_blocks=4, n_blocks_rows=64):
     return res
 
 
+def validator_set_leg(pkg, n_validators=150):
+    """the non-cryptographic half of a Tendermint commit check as a circuit (gadgets.validator_set_circuit): validators_hash of n validators
+    (variable-length protobuf leaves, RFC 6962 tree) on the SHA row gates + the > 2/3 voting-power rule; Ed25519 signatures are NOT constrained
+    (flags are witnesses; the GPU witness kernel checks them outside).  BASELINE configs[0]'s "validator-Merkle witness", constrained."""
+    import importlib
+    pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    gd = importlib.import_module(graft.PKG_NAME + ".gadgets")
+    bs = importlib.import_module(graft.PKG_NAME + ".blobstream")
+    pr = pkg.Prover(0)
+    pr.set_poseidon_constants(*(np.array(a, dtype=np.uint64) for a in pc.default_constants()))
+    rng = np.random.default_rng(13)
+    keys = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_validators)]
+    powers = [int(rng.integers(1, 1 << 40)) for _ in range(n_validators)]
+    signed = [bool(i % 5) for i in range(n_validators)]                      # 80 % of the validators sign
+    t0 = time.perf_counter()
+    ck, dw, public, digest = gd.validator_set_circuit(pr, keys, powers, signed)
+    pr.sync()
+    t1 = time.perf_counter()
+    proof = ck.prove_(dw, 28, 16, public=public)
+    t2 = time.perf_counter()
+    proof = ck.prove_(dw, 28, 16, public=public)
+    t3 = time.perf_counter()
+    ok = bool(ck.verify(proof, 28, 16, public=public))
+    res = {"validators": n_validators, "rows": 1 << ck.log_n, "wires": ck.n_wires, "build_circuit_seconds": round(t1 - t0, 3),
+           "prove_seconds_first": round(t2 - t1, 4), "prove_seconds": round(t3 - t2, 4), "verified": ok, "proof_bytes": len(proof),
+           "hash_matches_gpu_witness_kernel": digest == bs.validator_set_hash(pr, keys, powers),
+           "signed_power_over_total": round(public[8] / public[9], 4),
+           "note": "build-defined statement: validators_hash + the > 2/3 rule constrained; Ed25519 signatures of the flagged validators NOT constrained"}
+    dw.free()
+    ck.free()
+    pr.close()
+    return res
+
+
 def data_commitment_range_leg(pkg, rank, local_rank, world, blocks=4096, leaf_blocks=64, fan_in=8):
     """BASELINE configs[4] shape with a statement that MEANS something: the data commitment of a 4096-block range proved as a MapReduce of
     proofs (data_commitment_mr.py) — 64 leaves of 64 blocks on the SHA row gates (rank r proves the r-th contiguous part), each rank folds its
@@ -838,6 +872,10 @@ def main():
             out["data_commitment_circuit"] = data_commitment_leg(pkg)
         except Exception as e:  # noqa: BLE001
             out["data_commitment_circuit"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
+            out["validator_set_circuit"] = validator_set_leg(pkg)
+        except Exception as e:  # noqa: BLE001
+            out["validator_set_circuit"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_prove:
         # ... and the MapReduce shape of CombinedSkip (configs[2]/[3]): 16 leaf proofs per GPU + one all-gather,
         # on every rank.  A failure here must not cost the NTT line: it is reported instead.
