@@ -303,12 +303,7 @@ def validator_set_statement(b, g, pubkeys, voting_powers, signed, numerator=2, d
         b.assert_bool(f)
         flags.append(f)
 
-    def tree(nodes):
-        if len(nodes) == 1:
-            return nodes[0]
-        k = 1 << ((len(nodes) - 1).bit_length() - 1)                                      # largest power of two strictly below len
-        return g.hash_prefixed_64(0x01, tree(nodes[:k]) + tree(nodes[k:]))
-    root = tree(leaves)
+    root = rfc6962_root(g, leaves)
     total, got = powers[0], b.mul(flags[0], powers[0])
     for pw, f in zip(powers[1:], flags[1:]):
         total = b.add(total, pw)
@@ -322,6 +317,49 @@ def validator_set_statement(b, g, pubkeys, voting_powers, signed, numerator=2, d
     b.range32(b.arith(1, 0, 0, hi, b.constant(1 << 4), hi))
     b.assert_equal(b.arith(1, 1, 0, hi, g.c2_32, lo), d)
     return root, got, total
+
+
+def rfc6962_root(g, leaf_digests):
+    """RFC 6962 / Tendermint simple Merkle root over already-hashed leaves (8 word variables each): split at the largest power of two below n"""
+    if len(leaf_digests) == 1:
+        return leaf_digests[0]
+    k = 1 << ((len(leaf_digests) - 1).bit_length() - 1)
+    return g.hash_prefixed_64(0x01, rfc6962_root(g, leaf_digests[:k]) + rfc6962_root(g, leaf_digests[k:]))
+
+
+def header_hash_statement(b, g, fields, bound=None):
+    """a Tendermint-style header hash in-circuit: the RFC 6962 root over the header's encoded fields ([RECALLED] cometbft Header.Hash(): 14 leaves,
+    each the protobuf encoding of one field; here the encodings are opaque byte strings, which is all the hash depends on).  fields: list of bytes
+    (witnesses, range-checked); bound: {field index: [byte variables]} replaces a field's bytes by variables computed elsewhere in the circuit —
+    e.g. 0x0a 0x20 || validators_hash, which is what ties a header to a validator set.  Returns the 8 word variables of the header hash."""
+    bound = bound or {}
+    leaves = []
+    for k, fb in enumerate(fields):
+        bv = bound[k] if k in bound else [g.byte(b.var(v)) for v in bytes(fb)]
+        leaves.append(g.hash_bytes([b.constant(0x00)] + list(bv)))
+    return rfc6962_root(g, leaves)
+
+
+def commit_check_circuit(prover, header_fields, validators_field, pubkeys, voting_powers, signed):
+    """Skip/Step-shaped statement WITHOUT the signature half: public inputs = the 8 words of a header hash, then signed_power and total_power;
+    constraints = that header's field `validators_field` is BytesValue(validators_hash) of a validator set (hashed in-circuit from keys and powers)
+    whose flagged members hold more than 2/3 of the power.  That each flagged validator signed the header is NOT constrained (Ed25519 stays a GPU
+    witness check).  Returns (circuit, device wires, public values, header hash bytes, validators_hash bytes)."""
+    from . import SHA_GATE_WIRES
+    b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
+    g = Sha256Rows(b)
+    vroot, got, total = validator_set_statement(b, g, pubkeys, voting_powers, signed)
+    vbytes = [x for w in vroot for x in g.bytes_of_word(w)]
+    field = [b.constant(0x0a), b.constant(0x20)] + vbytes
+    hroot = header_hash_statement(b, g, header_fields, bound={validators_field: field})
+    for w in hroot:
+        b.public_input(w)
+    b.public_input(got)
+    b.public_input(total)
+    hh = b"".join(struct.pack(">I", b.value(w)) for w in hroot)
+    vh = b"".join(struct.pack(">I", b.value(w)) for w in vroot)
+    ck, dw, public = b.build()
+    return ck, dw, public, hh, vh
 
 
 def validator_set_circuit(prover, pubkeys, voting_powers, signed, numerator=2, denominator=3):

@@ -217,6 +217,63 @@ def test_validator_set_statement_on_the_builder(n):
                 prog.evaluate(consts, bad_inputs)
 
 
+def _tm_tree(leaves):
+    if len(leaves) == 1:
+        return hashlib.sha256(b"\x00" + leaves[0]).digest()
+    k = 1 << ((len(leaves) - 1).bit_length() - 1)
+    return hashlib.sha256(b"\x01" + _tm_tree(leaves[:k]) + _tm_tree(leaves[k:])).digest()
+
+
+def _header_fields(rng):
+    """14 opaque field encodings of realistic lengths (version, chain id, height, time, last block id, then nine 34-byte BytesValue hashes and a
+    22-byte address); index 7 is the validators_hash slot"""
+    lens = [4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22]
+    return [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
+
+
+def test_header_hash_binds_the_validator_set():
+    """a header's RFC 6962 root over 14 encoded fields laid down in-circuit, with field 7 bound to BytesValue(validators_hash) of a validator set
+    hashed in the same circuit: equals the hashlib restatement; a header carrying another validators_hash gives another public hash"""
+    gd, rec, bs = _mods()
+    rng = np.random.default_rng(77)
+    keys, powers = _validators(rng, 4)
+    fields = _header_fields(rng)
+    b = rec.CircuitBuilder(object(), n_wires=144)
+    g = gd.Sha256Rows(b)
+    vroot, got, total = gd.validator_set_statement(b, g, keys, powers, [True] * 4)
+    field7 = [b.constant(0x0a), b.constant(0x20)] + [x for w in vroot for x in g.bytes_of_word(w)]
+    hroot = gd.header_hash_statement(b, g, fields, bound={7: field7})
+    vh = _validators_hash(bs, keys, powers)
+    want = list(fields)
+    want[7] = b"\x0a\x20" + vh
+    assert b"".join(struct.pack(">I", b.value(w)) for w in hroot) == _tm_tree(want)
+    assert _tm_tree(want) != _tm_tree(fields)
+
+
+@pytest.mark.gpu
+def test_commit_check_circuit_proves(prover, oracle, pkg):
+    gd, rec, bs = _mods()
+    rc, circ, diag = poseidon_consts("small")
+    prover.set_poseidon_constants(rc, circ, diag)
+    oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
+    rng = np.random.default_rng(654)
+    keys, powers = _validators(rng, 5)
+    fields = _header_fields(rng)
+    ck, dw, public, hh, vh = gd.commit_check_circuit(prover, fields, 7, keys, powers, [True] * 5)
+    want = list(fields)
+    want[7] = b"\x0a\x20" + _validators_hash(bs, keys, powers)
+    assert vh == _validators_hash(bs, keys, powers) and hh == _tm_tree(want)
+    assert public[:8] == list(struct.unpack(">8I", hh)) and public[8] == public[9] == sum(powers)
+    proof = ck.prove_(dw, 10, 6, public=public)
+    assert ck.verify(proof, 10, 6, public=public), prover.last_reject
+    pref.verify_plonk(proof, oracle, pos_consts=(rc, circ, diag), public=public)
+    other = list(public)
+    other[0] ^= 1                                                       # another header
+    assert not ck.verify(proof, 10, 6, public=other)
+    dw.free()
+    ck.free()
+
+
 @pytest.mark.gpu
 def test_validator_set_circuit_proves(prover, oracle, pkg):
     gd, rec, bs = _mods()
