@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) glp_merkle_level_coop_kernel(const u64* _
     const bool active = node < count;
     u64 x = 0;
     if (active && r < 8u) x = prev[node * 8 + r];
-    x = glp_poseidon_permute_coop<SMALL>(x, r, lane_base, k);
+    if (((t >> 6) << 2) < count) x = glp_poseidon_permute_coop<SMALL>(x, r, lane_base, k);      // whole waves past the last node skip (wave-uniform)
     if (active && r < 4u) cur[node * 4 + r] = x;
 }
 
@@ -299,7 +299,10 @@ __global__ void __launch_bounds__(1024) glp_merkle_top_coop_kernel(u64* __restri
         const bool active = node < cnt;
         u64 x = 0;
         if (active && r < 8u) x = l ? buf[(l - 1) & 1][node * 8 + r] : prev[(u64)node * 8 + r];
-        x = glp_poseidon_permute_coop<SMALL>(x, r, lane_base, k);
+        // a wave (4 nodes) with no node left at this level sits the permutation out — the shuffles are wave-local, so only whole waves may —
+        // instead of sharing its SIMD's issue slots with the waves that still have work: the 16 waves of the workgroup sit 4 to a SIMD, and
+        // the upper levels need 8, 4, 2, 1, 1 of them (206 -> ~60 us per tree top)
+        if ((u64)((threadIdx.x >> 6) << 2) < cnt) x = glp_poseidon_permute_coop<SMALL>(x, r, lane_base, k);
         if (active && r < 4u) { cur[(u64)node * 4 + r] = x; buf[l & 1][node * 4 + r] = x; }
         __syncthreads();
         prev = cur;
