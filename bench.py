@@ -876,6 +876,28 @@ def main():
             out["validator_set_circuit"] = validator_set_leg(pkg)
         except Exception as e:  # noqa: BLE001
             out["validator_set_circuit"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # Everything below is extra to the contract's metric and runs collectives of its own on every rank.  An exception in a leg is reported in its
+    # object; a HANG (a peer lost inside a collective on some fabric this build never ran on) must not cost the line either: after
+    # GLP_BENCH_LEG_TIMEOUT seconds (default 600) rank 0 prints what it has, marks the legs as timed out, and every rank leaves.
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(float(os.environ.get("GLP_BENCH_LEG_TIMEOUT", "600"))):
+            return
+        if rank == 0:
+            for _ in range(20):                      # the main thread may be inserting a leg's result right now
+                try:
+                    line = json.dumps(dict(out, optional_legs_timed_out=True))
+                    break
+                except RuntimeError:
+                    time.sleep(0.05)
+            else:
+                line = json.dumps({k: v for k, v in list(out.items()) if k not in ("mapreduce", "data_commitment_range")} | {"optional_legs_timed_out": True})
+            print(line, flush=True)
+        os._exit(0)
+    if world > 1 and not args.no_prove:
+        threading.Thread(target=watchdog, daemon=True).start()
     if not args.no_prove:
         # ... and the MapReduce shape of CombinedSkip (configs[2]/[3]): 16 leaf proofs per GPU + one all-gather,
         # on every rank.  A failure here must not cost the NTT line: it is reported instead.
@@ -894,11 +916,15 @@ def main():
                 dcr = {"error": f"{type(e).__name__}: {e}"[:300]}
             if rank == 0:
                 out["data_commitment_range"] = dcr
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    done.set()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if world > 1:
+        try:                                             # the line is out: a peer that left early (watchdog) must not turn it into a failure
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":
