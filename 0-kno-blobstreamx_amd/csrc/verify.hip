@@ -636,9 +636,8 @@ static int witness_run(const Hasher& h, const u64* prog, size_t pc, size_t end, 
     };
     auto wr = [&](u64 v) {
         if constexpr (OWNED) {
-            const uint16_t o = __atomic_load_n(&owner[v], __ATOMIC_RELAXED);
-            if (o != 0xFFFF && o != me) return false;
-            __atomic_store_n(&owner[v], me, __ATOMIC_RELAXED);
+            uint16_t expected = 0xFFFF;                      // claim the variable: two segments racing for it cannot both succeed
+            if (!__atomic_compare_exchange_n(&owner[v], &expected, me, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED) && expected != me) return false;
         } else if (owner) owner[v] = me;
         return true;
     };
