@@ -164,6 +164,8 @@ class CircuitBuilder:
         outs = [self._new(int(v)) for v in out]
         if swap is None:
             self.prog += (6, *outs, *ins)
+            swap = self.constant(0)             # the row's swap cell is COPY-CONSTRAINED to zero: left free, a prover could set it (with matching
+            #                                     deltas) and hash the blocks in the other order
         else:
             self.prog += (12, *outs, *ins, swap)
         self.pos_rows.append((list(ins), outs, swap))
@@ -297,8 +299,7 @@ class WitnessProgram:
                 cj.append(j); ci.append(i); cv.append(v)
             for j, v in enumerate(outs):
                 cj.append(12 + j); ci.append(i); cv.append(v)
-            if swap is not None:
-                cj.append(24); ci.append(i); cv.append(swap)            # GLP_POS_SWAP_WIRE (an unused swap cell stays 0)
+            cj.append(24); ci.append(i); cv.append(swap)                # GLP_POS_SWAP_WIRE: an index bit, or the constant 0 (never a free cell)
             self.pos_row_ids.append(i)
             i += 1
         sha_ids, sha_kinds = [], []

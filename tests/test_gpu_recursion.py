@@ -339,3 +339,33 @@ def test_reduce_tree_spread_over_ranks(setup, pkg):
     f.free()
     dw.free()
     ck.free()
+
+
+def test_unswapped_poseidon_rows_pin_their_swap_cell_to_zero(setup, pkg):
+    """a Poseidon row's swap cell is an input of the row: where the builder does not use it, it is copy-constrained to the constant 0.  With
+    both halves equal the row itself is satisfied for either value of the bit (swapping equal blocks changes nothing), so only that copy
+    constraint stands between a prover and a row that hashes its blocks in the other order: flipping the cell must cost the proof."""
+    prover, oracle, rec, mr = setup
+    consts = poseidon_consts("small")
+    b = rec.CircuitBuilder(prover)
+    half = [b.var(v) for v in (11, 22, 33, 44)]
+    for v in b.two_to_one(half, half):
+        b.public_input(v)
+    prog = b.program()
+    ck = prog.setup(prover)
+    dw, public = prog.device_witness(prover, np.array(b.values, dtype=np.uint64))
+    assert ck.verify(ck.prove_(dw, 8, 4, public=public), 8, 4, public=public)
+    n = 1 << prog.log_n
+    w = dw.download((prog.W, n))
+    row = int(prog.pos_row_ids[0])
+    assert w[24, row] == 0
+    w[24, row] = 1                                           # the row's own 123 constraints still hold (deltas are 0: the halves are equal)
+    row_vals = [int(v) for v in w[:pref.POS_WIRES, row]]
+    assert not any(pref.poseidon_constraints(pref.Base, row_vals, pref.int_consts(consts)))
+    try:
+        bad = ck.prove(w, 8, 4, public=public)
+    except pkg.GlpError:
+        bad = None
+    assert bad is None or not ck.verify(bad, 8, 4, public=public)
+    dw.free()
+    ck.free()
