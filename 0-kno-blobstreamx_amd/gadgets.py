@@ -259,22 +259,15 @@ class Sha256Rows:
         return bs
 
 
-def validator_set_statement(b, g, pubkeys, voting_powers, signed, numerator=2, denominator=3):
-    """Lay down, on builder b (gadget g = Sha256Rows(b)), the non-cryptographic half of a Tendermint commit check ([RECALLED] tendermintx's
-    validator-set and voting-power logic; the encodings are [SPEC] protobuf / RFC 6962, as in blobstream.py):
-      * every validator's Merkle leaf 0x00 || SimpleValidator{pub_key{ed25519 = pubkey}, voting_power} is hashed in-circuit from its 32 key bytes
-        and its power's varint groups (7 bits each; the number of groups is a constant of the circuit, like the number of validators);
-      * the RFC 6962 tree over the leaves (split at the largest power of two below n) gives validators_hash;
-      * signed_power = sum of the powers whose `signed` flag is 1, total_power = the sum of all, and
-        denominator * signed_power > numerator * total_power  (a 60-bit non-negative difference, shown by range checks).
-    The flags are boolean WITNESSES: that a flagged validator's Ed25519 signature verifies is NOT constrained here (the GPU witness kernel checks it
-    outside the circuit; the curve arithmetic in-circuit is what upstream's STARK is for).  Powers must be below 2^49 (7 varint groups), so no sum can
-    wrap.  Returns (validators_hash: 8 word variables, signed_power, total_power)."""
+def _validator_set(b, g, pubkeys, voting_powers):
+    """hash a validator set in-circuit: returns {"root": 8 word variables (validators_hash), "keys": per validator its 32 byte variables,
+    "powers": per validator its power variable, "total": the sum}.  Leaves: 0x00 || SimpleValidator{pub_key{ed25519}, voting_power} with the
+    power's varint groups as range-checked 7-bit witnesses (their number is a constant of the circuit); powers < 2^49."""
     n = len(pubkeys)
-    assert n >= 1 and len(voting_powers) == n and len(signed) == n
+    assert n >= 1 and len(voting_powers) == n
     c128 = b.constant(128)
-    leaves, powers, flags = [], [], []
-    for key, power, sg in zip(pubkeys, voting_powers, signed):
+    leaves, powers, keys = [], [], []
+    for key, power in zip(pubkeys, voting_powers):
         power = int(power)
         if not 0 < power < (1 << 49) or len(key) != 32:
             raise ValueError("validator: 32-byte key and 0 < voting power < 2^49 expected")
@@ -299,16 +292,16 @@ def validator_set_statement(b, g, pubkeys, voting_powers, signed, numerator=2, d
         leaf = [b.constant(v) for v in (0x00, 0x0a, 0x22, 0x0a, 0x20)] + kb + [b.constant(0x10)] + vbytes
         leaves.append(g.hash_bytes(leaf))
         powers.append(pw)
-        f = b.var(1 if sg else 0)
-        b.assert_bool(f)
-        flags.append(f)
-
-    root = rfc6962_root(g, leaves)
-    total, got = powers[0], b.mul(flags[0], powers[0])
-    for pw, f in zip(powers[1:], flags[1:]):
+        keys.append(kb)
+    total = powers[0]
+    for pw in powers[1:]:
         total = b.add(total, pw)
-        got = b.arith(1, 1, 0, f, pw, got)
-    # d = denominator * signed - numerator * total - 1 >= 0, d < 2^60:  d = hi * 2^32 + lo with lo < 2^32, hi < 2^28
+    return {"root": rfc6962_root(g, leaves), "keys": keys, "powers": powers, "total": total}
+
+
+def _more_than(b, g, got, total, numerator, denominator):
+    """denominator * got > numerator * total for sums below 2^57:  d = denominator * got - numerator * total - 1 is shown to be a non-negative
+    60-bit number (d = hi * 2^32 + lo, lo < 2^32, hi < 2^28): a negative difference is p - k > 2^63 and has no such decomposition"""
     d = b.arith(0, denominator, P - 1, got, got, got)
     d = b.arith(1, 1, 0, total, b.constant(P - numerator), d)
     lo, hi = b.bit_field(d, 0, 32), b.bit_field(d, 32, 28)
@@ -316,7 +309,82 @@ def validator_set_statement(b, g, pubkeys, voting_powers, signed, numerator=2, d
     b.range32(hi)
     b.range32(b.arith(1, 0, 0, hi, b.constant(1 << 4), hi))
     b.assert_equal(b.arith(1, 1, 0, hi, g.c2_32, lo), d)
-    return root, got, total
+
+
+def _flags(b, signed):
+    out = []
+    for sg in signed:
+        f = b.var(1 if sg else 0)
+        b.assert_bool(f)
+        out.append(f)
+    return out
+
+
+def validator_set_statement(b, g, pubkeys, voting_powers, signed, numerator=2, denominator=3):
+    """Lay down, on builder b (gadget g = Sha256Rows(b)), the non-cryptographic half of a Tendermint commit check ([RECALLED] tendermintx's
+    validator-set and voting-power logic; the encodings are [SPEC] protobuf / RFC 6962, as in blobstream.py):
+      * every validator's Merkle leaf 0x00 || SimpleValidator{pub_key{ed25519 = pubkey}, voting_power} is hashed in-circuit from its 32 key bytes
+        and its power's varint groups (7 bits each; the number of groups is a constant of the circuit, like the number of validators);
+      * the RFC 6962 tree over the leaves (split at the largest power of two below n) gives validators_hash;
+      * signed_power = sum of the powers whose `signed` flag is 1, total_power = the sum of all, and
+        denominator * signed_power > numerator * total_power  (a 60-bit non-negative difference, shown by range checks).
+    The flags are boolean WITNESSES: that a flagged validator's Ed25519 signature verifies is NOT constrained here (the GPU witness kernel checks it
+    outside the circuit; the curve arithmetic in-circuit is what upstream's STARK is for).  Powers must be below 2^49 (7 varint groups), so no sum can
+    wrap.  Returns (validators_hash: 8 word variables, signed_power, total_power).
+    Input order of the recorded program: per validator its 32 key bytes then its varint groups; then the flags."""
+    vs = _validator_set(b, g, pubkeys, voting_powers)
+    flags = _flags(b, signed)
+    got = b.mul(flags[0], vs["powers"][0])
+    for pw, f in zip(vs["powers"][1:], flags[1:]):
+        got = b.arith(1, 1, 0, f, pw, got)
+    _more_than(b, g, got, vs["total"], numerator, denominator)
+    return vs["root"], got, vs["total"]
+
+
+def skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index):
+    """The non-cryptographic statement of a light-client SKIP ([RECALLED] tendermintx verify_skip; blobstream.skip_witness computes the same as a
+    witness): from a trusted header to a target header that need not be its successor,
+      1. the trusted header's next_validators_hash field (index 8) is BytesValue(hash of the trusted set),
+      2. the target header's validators_hash field (index 7) is BytesValue(hash of the target set),
+      3. the flagged target validators hold more than 2/3 of the target set's power,
+      4. flagged target validators that are ALSO in the trusted set (trusted_index[i] = their position there, or None; same 32 key bytes, enforced
+         by copy constraints) hold more than 1/3 of the TRUSTED set's power.
+    trusted / target = (pubkeys, voting_powers); header fields = 14 opaque byte strings each (the bound field's own bytes are ignored).
+    NOT constrained: that the flagged validators signed the target header (Ed25519).  Returns (trusted header hash, target header hash): 8 word
+    variables each."""
+    T = _validator_set(b, g, *trusted)
+    V = _validator_set(b, g, *target)
+    flags = _flags(b, signed)
+    zero = b.constant(0)
+    got, overlap = zero, zero
+    for i, f in enumerate(flags):
+        got = b.arith(1, 1, 0, f, V["powers"][i], got)
+        t = trusted_index[i]
+        if t is not None:
+            for x, y in zip(V["keys"][i], T["keys"][t]):
+                b.assert_equal(x, y)                                   # the same validator: the same 32 key bytes
+            overlap = b.arith(1, 1, 0, f, T["powers"][t], overlap)
+    _more_than(b, g, got, V["total"], 2, 3)
+    _more_than(b, g, overlap, T["total"], 1, 3)
+    wrap = lambda root: [b.constant(0x0a), b.constant(0x20)] + [x for w in root for x in g.bytes_of_word(w)]
+    h_trusted = header_hash_statement(b, g, trusted_header_fields, bound={8: wrap(T["root"])})
+    h_target = header_hash_statement(b, g, target_header_fields, bound={7: wrap(V["root"])})
+    return h_trusted, h_target
+
+
+def skip_circuit(prover, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index):
+    """the circuit of skip_statement: public inputs = the trusted header hash then the target header hash (8 words each).  Returns (circuit,
+    device wires, public values, trusted header hash bytes, target header hash bytes); ValueError when a threshold is not met."""
+    from . import SHA_GATE_WIRES
+    b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
+    g = Sha256Rows(b)
+    ht, hv = skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index)
+    for w in ht + hv:
+        b.public_input(w)
+    to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
+    hb_t, hb_v = to_bytes(ht), to_bytes(hv)
+    ck, dw, public = b.build()
+    return ck, dw, public, hb_t, hb_v
 
 
 def rfc6962_root(g, leaf_digests):

@@ -188,15 +188,19 @@ def test_validator_set_statement_on_the_builder(n):
     prog = b.program()
     # replay: same shape (same varint lengths), other keys, flags unchanged
     keys2 = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n)]
-    inputs = []
-    for k2, p, sg in zip(keys2, powers, signed):
-        groups = []
-        while True:
-            groups.append(p & 0x7F)
-            p >>= 7
-            if not p:
-                break
-        inputs += list(k2) + groups + [1 if sg else 0]
+    def program_inputs(ks, flags):
+        """per validator its 32 key bytes then its varint groups; then the flags (the order the statement records them in)"""
+        out = []
+        for k2, p in zip(ks, powers):
+            groups = []
+            while True:
+                groups.append(p & 0x7F)
+                p >>= 7
+                if not p:
+                    break
+            out += list(k2) + groups
+        return out + [1 if sg else 0 for sg in flags]
+    inputs = program_inputs(keys2, signed)
     vals = prog.evaluate(consts, inputs)
     assert b"".join(struct.pack(">I", int(vals[w])) for w in root) == _validators_hash(bs, keys2, powers)
     if n > 1:
@@ -207,14 +211,8 @@ def test_validator_set_statement_on_the_builder(n):
             with pytest.raises(ValueError, match="assert_equal"):
                 gd.validator_set_statement(b3, gd.Sha256Rows(b3), keys, powers, weak)
             # ... and the recorded program refuses those flags too (the range check of the difference fails)
-            bad_inputs = list(inputs)
-            pos = 0
-            for i, p in enumerate(powers):
-                ng = max(1, (p.bit_length() + 6) // 7)
-                bad_inputs[pos + 32 + ng] = 1 if weak[i] else 0
-                pos += 32 + ng + 1
             with pytest.raises(ValueError):
-                prog.evaluate(consts, bad_inputs)
+                prog.evaluate(consts, program_inputs(keys2, weak))
 
 
 def _tm_tree(leaves):
@@ -248,6 +246,74 @@ def test_header_hash_binds_the_validator_set():
     want[7] = b"\x0a\x20" + vh
     assert b"".join(struct.pack(">I", b.value(w)) for w in hroot) == _tm_tree(want)
     assert _tm_tree(want) != _tm_tree(fields)
+
+
+def _skip_case(rng, n_trusted=4, n_target=5):
+    """a trusted set, a target set sharing its first three members (other powers), headers, flags: all target validators but the last sign"""
+    tk, tp = _validators(rng, n_trusted)
+    vk, vp = _validators(rng, n_target)
+    idx = [None] * n_target
+    for i in range(3):
+        vk[i] = tk[i]
+        idx[i] = i
+    tp = [1000, 900, 800, 50][:n_trusted]
+    signed = [True] * (n_target - 1) + [False]
+    vp = [700, 600, 500, 400, 100][:n_target]
+    return tk, tp, vk, vp, idx, signed, _header_fields(rng), _header_fields(rng)
+
+
+def test_skip_statement_on_the_builder():
+    """the whole non-cryptographic skip statement: both headers bound to their validator sets, > 2/3 of the target power flagged, > 1/3 of the
+    TRUSTED power held by flagged validators present in both sets (same key bytes by copy constraints); each broken premise cannot be laid down"""
+    gd, rec, bs = _mods()
+    rng = np.random.default_rng(88)
+    tk, tp, vk, vp, idx, signed, hf_t, hf_v = _skip_case(rng)
+    b = rec.CircuitBuilder(object(), n_wires=144)
+    g = gd.Sha256Rows(b)
+    ht, hv = gd.skip_statement(b, g, hf_t, (tk, tp), hf_v, (vk, vp), signed, idx)
+    want_t, want_v = list(hf_t), list(hf_v)
+    want_t[8] = b"\x0a\x20" + _validators_hash(bs, tk, tp)
+    want_v[7] = b"\x0a\x20" + _validators_hash(bs, vk, vp)
+    to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
+    assert to_bytes(ht) == _tm_tree(want_t) and to_bytes(hv) == _tm_tree(want_v)
+
+    def fails(**kw):
+        args = dict(signed=signed, idx=idx, vk=vk)
+        args.update(kw)
+        bb = rec.CircuitBuilder(object(), n_wires=144)
+        with pytest.raises(ValueError):
+            gd.skip_statement(bb, gd.Sha256Rows(bb), hf_t, (tk, tp), hf_v, (args["vk"], vp), args["signed"], args["idx"])
+    fails(signed=[True, False, False, False, False])                          # 700 of 2300: not > 2/3 of the target set
+    fails(signed=[False, False, True, True, True])                            # 1000 of 2300 target power... and only 800 of 2750 trusted: not > 1/3
+    other = list(vk)
+    other[1] = bytes(32)
+    fails(vk=other)                                                           # "validator 1 is trusted validator 1" with another key
+    # enough target power but too little TRUSTED power: validators 3 and 4 are not in the trusted set
+    fails(signed=[False, True, True, True, True], idx=[None, 1, None, None, None])
+
+
+@pytest.mark.gpu
+def test_skip_circuit_proves(prover, oracle, pkg):
+    gd, rec, bs = _mods()
+    rc, circ, diag = poseidon_consts("small")
+    prover.set_poseidon_constants(rc, circ, diag)
+    oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
+    rng = np.random.default_rng(89)
+    tk, tp, vk, vp, idx, signed, hf_t, hf_v = _skip_case(rng)
+    ck, dw, public, hb_t, hb_v = gd.skip_circuit(prover, hf_t, (tk, tp), hf_v, (vk, vp), signed, idx)
+    want_t, want_v = list(hf_t), list(hf_v)
+    want_t[8] = b"\x0a\x20" + bs.validator_set_hash(prover, tk, tp)           # the GPU witness kernel's hashes
+    want_v[7] = b"\x0a\x20" + bs.validator_set_hash(prover, vk, vp)
+    assert hb_t == _tm_tree(want_t) and hb_v == _tm_tree(want_v)
+    assert public == list(struct.unpack(">8I", hb_t)) + list(struct.unpack(">8I", hb_v))
+    proof = ck.prove_(dw, 10, 6, public=public)
+    assert ck.verify(proof, 10, 6, public=public), prover.last_reject
+    pref.verify_plonk(proof, oracle, pos_consts=(rc, circ, diag), public=public)
+    other = list(public)
+    other[15] ^= 1
+    assert not ck.verify(proof, 10, 6, public=other)
+    dw.free()
+    ck.free()
 
 
 @pytest.mark.gpu
