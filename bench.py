@@ -656,6 +656,46 @@ def validator_set_leg(pkg, n_validators=150):
     return res
 
 
+def skip_leg(pkg, n_validators=100):
+    """the non-cryptographic statement of a light-client skip as ONE circuit (gadgets.skip_circuit): a trusted and a target header (14 field
+    encodings each) bound to their validator sets, > 2/3 of the target power and > 1/3 of the trusted power flagged — CombinedSkip's shape minus
+    its Ed25519 half (NOT constrained).  The target set keeps 90 % of the trusted set's members."""
+    import importlib
+    pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    gd = importlib.import_module(graft.PKG_NAME + ".gadgets")
+    pr = pkg.Prover(0)
+    pr.set_poseidon_constants(*(np.array(a, dtype=np.uint64) for a in pc.default_constants()))
+    rng = np.random.default_rng(14)
+    key = lambda: rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+    tk = [key() for _ in range(n_validators)]
+    tp = [int(rng.integers(1, 1 << 40)) for _ in range(n_validators)]
+    keep = n_validators * 9 // 10
+    vk = tk[:keep] + [key() for _ in range(n_validators - keep)]
+    vp = [int(rng.integers(1, 1 << 40)) for _ in range(n_validators)]
+    idx = list(range(keep)) + [None] * (n_validators - keep)
+    signed = [bool(i % 7) for i in range(n_validators)]
+    lens = [4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22]
+    fields = lambda: [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
+    t0 = time.perf_counter()
+    ck, dw, public, hb_t, hb_v = gd.skip_circuit(pr, fields(), (tk, tp), fields(), (vk, vp), signed, idx)
+    pr.sync()
+    t1 = time.perf_counter()
+    proof = ck.prove_(dw, 28, 16, public=public)
+    t2 = time.perf_counter()
+    proof = ck.prove_(dw, 28, 16, public=public)
+    t3 = time.perf_counter()
+    ok = bool(ck.verify(proof, 28, 16, public=public))
+    res = {"validators_per_set": n_validators, "shared_validators": keep, "rows": 1 << ck.log_n, "wires": ck.n_wires,
+           "build_circuit_seconds": round(t1 - t0, 3), "prove_seconds_first": round(t2 - t1, 4), "prove_seconds": round(t3 - t2, 4),
+           "verified": ok, "proof_bytes": len(proof), "public_inputs": len(public),
+           "note": "build-defined statement: both header hashes public; validator-set hashes, header binding and the 2/3 + 1/3 power rules constrained; "
+                   "Ed25519 signatures of the flagged validators NOT constrained"}
+    dw.free()
+    ck.free()
+    pr.close()
+    return res
+
+
 def data_commitment_range_leg(pkg, rank, local_rank, world, blocks=4096, leaf_blocks=64, fan_in=8):
     """BASELINE configs[4] shape with a statement that MEANS something: the data commitment of a 4096-block range proved as a MapReduce of
     proofs (data_commitment_mr.py) — 64 leaves of 64 blocks on the SHA row gates (rank r proves the r-th contiguous part), each rank folds its
@@ -876,6 +916,10 @@ def main():
             out["validator_set_circuit"] = validator_set_leg(pkg)
         except Exception as e:  # noqa: BLE001
             out["validator_set_circuit"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
+            out["skip_circuit"] = skip_leg(pkg)
+        except Exception as e:  # noqa: BLE001
+            out["skip_circuit"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     # Everything below is extra to the contract's metric and runs collectives of its own on every rank.  An exception in a leg is reported in its
     # object; a HANG (a peer lost inside a collective on some fabric this build never ran on) must not cost the line either: after
     # GLP_BENCH_LEG_TIMEOUT seconds (default 600) rank 0 prints what it has, marks the legs as timed out, and every rank leaves.
