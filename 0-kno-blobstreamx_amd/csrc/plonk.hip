@@ -144,8 +144,12 @@ extern "C" int glp_poseidon_gate_fill_rows(glp_ctx* c, uint64_t* d_wire_vals, ui
     if (!d_wire_vals || (!d_rows && n_rows) || log_n > 24 || n_wires < GLP_POS_GATE_WIRES) { glp_set_err(c, "glp_poseidon_gate_fill_rows: bad argument"); return GLP_E_INVALID; }
     if (!c->hash || !c->hash->have_consts) { glp_set_err(c, "Poseidon constants not set"); return GLP_E_STATE; }
     if (n_rows == 0) return GLP_OK;
-    hipLaunchKernelGGL(glp_poseidon_gate_fill_kernel<0>, dim3((n_rows + 63) / 64), dim3(64), 0, c->stream, d_wire_vals, 1ull << log_n, d_rows, n_rows,
-                       c->hash->d_consts);
+    if (c->hash->small_mds && !getenv("GLP_K7_GENERIC_MDS"))
+        hipLaunchKernelGGL(glp_poseidon_gate_fill_kernel<1>, dim3((n_rows + 63) / 64), dim3(64), 0, c->stream, d_wire_vals, 1ull << log_n, d_rows, n_rows,
+                           c->hash->d_consts);
+    else
+        hipLaunchKernelGGL(glp_poseidon_gate_fill_kernel<0>, dim3((n_rows + 63) / 64), dim3(64), 0, c->stream, d_wire_vals, 1ull << log_n, d_rows, n_rows,
+                           c->hash->d_consts);
     GLP_HIPCHK(c, hipGetLastError());
     return GLP_OK;
 }

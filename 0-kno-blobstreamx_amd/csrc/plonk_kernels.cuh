@@ -347,7 +347,42 @@ __global__ void __launch_bounds__(64) glp_sha_gate_fill_kernel(u64* __restrict__
 
 // ---- Poseidon-row witness: for each listed row, wires 12..134 from wires 0..11 and the swap bit in wire 24 (plonk_gates.h) ----
 // wires: [W][n] values on the trace domain; rows: n_rows row indices; consts: rc[360], circ[12], diag[12] (device)
-template <int UNUSED = 0>
+// SMALL_MDS: the permutation kernels' arithmetic (S-boxes on arbitrary representatives, small-integer MDS accumulators), every stored value
+// canonicalised — the same values as glp_poseidon_gate_fill (the definition, used when the MDS is not small; tests compare both with the
+// restatement), at a sixth of the instructions (117k -> ~20k VALU per row).
+template <bool SMALL_MDS>
+GL_HD void glp_poseidon_gate_fill_fast(const u64 (&in_)[12], u64 swap, const u64* rc, const u64* circ, const u64* diag, u64 (&out)[GLP_POS_GATE_WIRES - 12]) {
+    u64 in[12], s[12];
+    for (int i = 0; i < 12; i++) in[i] = in_[i];
+    out[12] = swap;
+    for (int i = 0; i < 4; i++) {
+        const u64 d = gl_mul(swap, gl_sub(in[4 + i], in[i]));
+        out[GLP_POS_DELTA0 - 12 + i] = d;
+        in[i] = gl_add(in[i], d);
+        in[4 + i] = gl_sub(in[4 + i], d);
+    }
+    for (int i = 0; i < 12; i++) s[i] = gl_add(in[i], rc[i]);
+    int rnd = 0, aw = GLP_POS_ADVICE0 - 12;
+    for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
+        if (r > 0) { for (int i = 0; i < 12; i++) { s[i] = gl_canon(s[i]); out[aw + i] = s[i]; } aw += 12; }
+        for (int i = 0; i < 12; i++) s[i] = glp_sbox7(s[i]);
+        glp_mds_layer<SMALL_MDS>(s, circ, diag, rc + (rnd + 1) * 12);
+    }
+    for (int r = 0; r < GLP_POS_PARTIAL; r++, rnd++) {
+        s[0] = gl_canon(s[0]);
+        out[aw++] = s[0];
+        s[0] = glp_sbox7(s[0]);
+        glp_mds_layer<SMALL_MDS>(s, circ, diag, rc + (rnd + 1) * 12);
+    }
+    for (int r = 0; r < GLP_POS_FULL_HALF; r++, rnd++) {
+        for (int i = 0; i < 12; i++) { s[i] = gl_canon(s[i]); out[aw + i] = s[i]; s[i] = glp_sbox7(s[i]); }
+        aw += 12;
+        glp_mds_layer<SMALL_MDS>(s, circ, diag, rnd + 1 < GLP_POS_ROUNDS ? rc + (rnd + 1) * 12 : nullptr);
+    }
+    for (int i = 0; i < 12; i++) out[i] = gl_canon(s[i]);
+}
+
+template <int SMALL_MDS = 0>
 __global__ void __launch_bounds__(64) glp_poseidon_gate_fill_kernel(u64* __restrict__ wires, u64 n, const u32* __restrict__ rows, u32 n_rows,
                                                                    const u64* __restrict__ consts) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,7 +391,9 @@ __global__ void __launch_bounds__(64) glp_poseidon_gate_fill_kernel(u64* __restr
     if (row >= n) return;
     u64 in[12], out[GLP_POS_GATE_WIRES - 12];
     for (int j = 0; j < 12; j++) in[j] = wires[(u64)j * n + row];
-    glp_poseidon_gate_fill(in, wires[(u64)GLP_POS_SWAP_WIRE * n + row], consts, consts + 360, consts + 372, out);
+    const u64 swap = wires[(u64)GLP_POS_SWAP_WIRE * n + row];
+    if constexpr (SMALL_MDS != 0) glp_poseidon_gate_fill_fast<true>(in, swap, consts, consts + 360, consts + 372, out);
+    else glp_poseidon_gate_fill(in, swap, consts, consts + 360, consts + 372, out);
     for (int j = 0; j < GLP_POS_GATE_WIRES - 12; j++) wires[(u64)(12 + j) * n + row] = out[j];
 }
 

@@ -358,7 +358,30 @@ extern "C" int emu_sha_gate_fill_rows(u64* wires, u32 log_n, const u32* rows, co
 
 // Poseidon-row witness through the product's kernel: wires [W][n] in place, for the listed rows
 extern "C" int emu_poseidon_gate_fill_rows(u64* wires, u32 log_n, const u32* rows, u32 n_rows, const u64* pos_consts) {
-    glp_emu_launch((n_rows + 63) / 64, 64, 0, [&] { glp_poseidon_gate_fill_kernel<0>(wires, 1ull << log_n, rows, n_rows, pos_consts); });
+    // the definition first, then (small MDS) the fast form the product launches: both must write the same wires
+    const u64 n = 1ull << log_n;
+    bool small = true;
+    unsigned __int128 sum = 0;
+    u64 maxdiag = 0;
+    for (int i = 0; i < 12; i++) {
+        const u64 cv = pos_consts[360 + i], dv = pos_consts[372 + i];
+        if (cv >> 24 || dv >> 24) small = false;
+        sum += cv;
+        if (dv > maxdiag) maxdiag = dv;
+    }
+    if (sum + maxdiag >= ((unsigned __int128)1 << 24)) small = false;
+    u32 W = 0;
+    for (u32 k = 0; k < n_rows; k++) (void)rows[k];
+    W = GLP_POS_GATE_WIRES;                              // the rows' Poseidon wires are all this function touches
+    std::vector<u64> before((size_t)W * n);
+    for (size_t i = 0; i < before.size(); i++) before[i] = wires[i];
+    glp_emu_launch((n_rows + 63) / 64, 64, 0, [&] { glp_poseidon_gate_fill_kernel<0>(wires, n, rows, n_rows, pos_consts); });
+    if (small) {
+        std::vector<u64> generic((size_t)W * n);
+        for (size_t i = 0; i < generic.size(); i++) { generic[i] = wires[i]; wires[i] = before[i]; }
+        glp_emu_launch((n_rows + 63) / 64, 64, 0, [&] { glp_poseidon_gate_fill_kernel<1>(wires, n, rows, n_rows, pos_consts); });
+        for (size_t i = 0; i < generic.size(); i++) if (generic[i] != wires[i]) return 2;
+    }
     return 0;
 }
 
