@@ -372,6 +372,45 @@ def skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, t
     return h_trusted, h_target
 
 
+def step_statement(b, g, trusted_header_fields, target_header_fields, validators, signed):
+    """The non-cryptographic statement of a light-client STEP ([RECALLED] tendermintx verify_step): the target header is the trusted header's
+    successor —
+      1. the trusted header's next_validators_hash (field 8) and the target header's validators_hash (field 7) are BytesValue(hash of ONE set),
+      2. the target header's last_block_id (field 4: 0x0a 0x20 || block hash || part-set header, 72 bytes) carries the TRUSTED header's hash —
+         the bytes of the hash computed in this circuit, so the chain link is constrained, not asserted,
+      3. the flagged validators hold more than 2/3 of the set's power.
+    validators = (pubkeys, voting_powers).  The last 38 bytes of the target's field 4 (0x12 0x24 || part-set header) stay opaque witnesses.
+    NOT constrained: the Ed25519 signatures.  Returns (trusted header hash, target header hash): 8 word variables each."""
+    V = _validator_set(b, g, *validators)
+    flags = _flags(b, signed)
+    got = b.constant(0)
+    for f, pw in zip(flags, V["powers"]):
+        got = b.arith(1, 1, 0, f, pw, got)
+    _more_than(b, g, got, V["total"], 2, 3)
+    wrap = lambda ws: [b.constant(0x0a), b.constant(0x20)] + [x for w in ws for x in g.bytes_of_word(w)]
+    h_trusted = header_hash_statement(b, g, trusted_header_fields, bound={8: wrap(V["root"])})
+    tail = bytes(target_header_fields[4])[34:]
+    if len(bytes(target_header_fields[4])) < 34:
+        raise ValueError("the target header's last_block_id field is shorter than 0x0a 0x20 || hash")
+    block_id = wrap(h_trusted) + [g.byte(b.var(v)) for v in tail]
+    h_target = header_hash_statement(b, g, target_header_fields, bound={7: wrap(V["root"]), 4: block_id})
+    return h_trusted, h_target
+
+
+def step_circuit(prover, trusted_header_fields, target_header_fields, validators, signed):
+    """the circuit of step_statement: public inputs = the trusted header hash then the target header hash (8 words each)"""
+    from . import SHA_GATE_WIRES
+    b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
+    g = Sha256Rows(b)
+    ht, hv = step_statement(b, g, trusted_header_fields, target_header_fields, validators, signed)
+    for w in ht + hv:
+        b.public_input(w)
+    to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
+    hb_t, hb_v = to_bytes(ht), to_bytes(hv)
+    ck, dw, public = b.build()
+    return ck, dw, public, hb_t, hb_v
+
+
 def skip_circuit(prover, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index):
     """the circuit of skip_statement: public inputs = the trusted header hash then the target header hash (8 words each).  Returns (circuit,
     device wires, public values, trusted header hash bytes, target header hash bytes); ValueError when a threshold is not met."""

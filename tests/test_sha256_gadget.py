@@ -292,6 +292,82 @@ def test_skip_statement_on_the_builder():
     fails(signed=[False, True, True, True, True], idx=[None, 1, None, None, None])
 
 
+def test_step_statement_links_the_headers():
+    """the step statement: one validator set behind the trusted header's next_validators_hash and the target header's validators_hash, and the
+    target's last_block_id carrying the trusted header's hash AS COMPUTED IN THE CIRCUIT; equals the hashlib restatement"""
+    gd, rec, bs = _mods()
+    rng = np.random.default_rng(90)
+    keys, powers = _validators(rng, 4)
+    hf_t, hf_v = _header_fields(rng), _header_fields(rng)
+    b = rec.CircuitBuilder(object(), n_wires=144)
+    g = gd.Sha256Rows(b)
+    ht, hv = gd.step_statement(b, g, hf_t, hf_v, (keys, powers), [True] * 4)
+    vh = _validators_hash(bs, keys, powers)
+    want_t = list(hf_t)
+    want_t[8] = b"\x0a\x20" + vh
+    trusted_hash = _tm_tree(want_t)
+    want_v = list(hf_v)
+    want_v[7] = b"\x0a\x20" + vh
+    want_v[4] = b"\x0a\x20" + trusted_hash + hf_v[4][34:]
+    to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
+    assert to_bytes(ht) == trusted_hash and to_bytes(hv) == _tm_tree(want_v)
+    # the recorded program follows another trusted header through the link: change one opaque byte of the trusted header.
+    # Input order: per validator 32 key bytes + varint groups, the flags, the trusted header's witness bytes field by field, the tail of the
+    # target's last_block_id, then the target's other fields
+    prog = b.program()
+    consts = poseidon_consts("small")
+    vec = []
+    for kk, p in zip(keys, powers):
+        groups = []
+        while True:
+            groups.append(p & 0x7F)
+            p >>= 7
+            if not p:
+                break
+        vec += list(kk) + groups
+    first_header_byte = len(vec) + 4
+    vec += [1] * 4
+    vec += [v for k, fb in enumerate(hf_t) if k != 8 for v in fb]
+    vec += list(hf_v[4][34:])                                                # the opaque tail of the target's last_block_id is recorded first
+    vec += [v for k, fb in enumerate(hf_v) if k not in (4, 7) for v in fb]
+    assert len(vec) == prog.n_inputs
+    vals = prog.evaluate(consts, vec)
+    assert b"".join(struct.pack(">I", int(vals[w])) for w in hv) == _tm_tree(want_v)
+    vec2 = list(vec)
+    vec2[first_header_byte] ^= 1                                            # first byte of the trusted header's field 0
+    vals2 = prog.evaluate(consts, vec2)
+    new_t = b"".join(struct.pack(">I", int(vals2[w])) for w in ht)
+    new_v = b"".join(struct.pack(">I", int(vals2[w])) for w in hv)
+    assert new_t != trusted_hash and new_v != _tm_tree(want_v)                         # the target's hash moves with the trusted header's
+    want_v2 = list(want_v)
+    want_v2[4] = b"\x0a\x20" + new_t + hf_v[4][34:]
+    assert new_v == _tm_tree(want_v2)
+
+
+@pytest.mark.gpu
+def test_step_circuit_proves(prover, oracle, pkg):
+    gd, rec, bs = _mods()
+    rc, circ, diag = poseidon_consts("small")
+    prover.set_poseidon_constants(rc, circ, diag)
+    oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
+    rng = np.random.default_rng(91)
+    keys, powers = _validators(rng, 5)
+    hf_t, hf_v = _header_fields(rng), _header_fields(rng)
+    ck, dw, public, hb_t, hb_v = gd.step_circuit(prover, hf_t, hf_v, (keys, powers), [True] * 5)
+    vh = bs.validator_set_hash(prover, keys, powers)
+    want_t = list(hf_t)
+    want_t[8] = b"\x0a\x20" + vh
+    want_v = list(hf_v)
+    want_v[7] = b"\x0a\x20" + vh
+    want_v[4] = b"\x0a\x20" + _tm_tree(want_t) + hf_v[4][34:]
+    assert hb_t == _tm_tree(want_t) and hb_v == _tm_tree(want_v)
+    proof = ck.prove_(dw, 10, 6, public=public)
+    assert ck.verify(proof, 10, 6, public=public), prover.last_reject
+    pref.verify_plonk(proof, oracle, pos_consts=(rc, circ, diag), public=public)
+    dw.free()
+    ck.free()
+
+
 @pytest.mark.gpu
 def test_skip_circuit_proves(prover, oracle, pkg):
     gd, rec, bs = _mods()
