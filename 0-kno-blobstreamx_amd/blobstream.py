@@ -94,6 +94,23 @@ def verify_signatures(prover, pubkeys, signatures, sign_bytes):
     return valid, rec
 
 
+def verify_signers(prover, poseidon_consts, signer_digest, pubkeys, signed, signatures, sign_bytes):
+    """The hybrid half of a commit check whose proof does NOT constrain Ed25519 (gadgets.step_circuit / skip_circuit): the proof's public inputs
+    carry a digest of (target validator keys, signed flags); the consumer, who holds the keys, the flags and the signatures, checks that
+      1. the digest of (pubkeys, signed) IS the proof's signer digest — the proof's power rules were about exactly these flags, and
+      2. every FLAGGED validator's signature verifies ([SPEC] RFC 8032, on the GPU witness kernel) over its sign bytes.
+    Unflagged validators need no signature.  Returns True / False."""
+    import importlib
+    gd = importlib.import_module(__package__ + ".gadgets")
+    if [int(v) for v in signer_digest] != gd.signer_digest_host(poseidon_consts, pubkeys, signed):
+        return False
+    flagged = [i for i, sg in enumerate(signed) if sg]
+    if any(signatures[i] is None for i in flagged):
+        return False
+    valid, _ = verify_signatures(prover, [pubkeys[i] for i in flagged], [signatures[i] for i in flagged], [sign_bytes[i] for i in flagged])
+    return bool(all(valid))
+
+
 def voting_power_check(voting_powers, signed, numerator, denominator):
     """signed_power * denominator > total_power * numerator, in exact integers ([RECALLED] Tendermint's
     "more than 2/3" commit rule and the light client's "more than 1/3 of the trusted set" skipping rule).

@@ -350,8 +350,9 @@ def skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, t
       4. flagged target validators that are ALSO in the trusted set (trusted_index[i] = their position there, or None; same 32 key bytes, enforced
          by copy constraints) hold more than 1/3 of the TRUSTED set's power.
     trusted / target = (pubkeys, voting_powers); header fields = 14 opaque byte strings each (the bound field's own bytes are ignored).
-    NOT constrained: that the flagged validators signed the target header (Ed25519).  Returns (trusted header hash, target header hash): 8 word
-    variables each."""
+    NOT constrained: that the flagged validators signed the target header (Ed25519) — but the proof exposes WHO was flagged (signer digest over
+    the target set's keys and flags), so a consumer checks exactly those signatures natively (blobstream.verify_signers).  Returns (trusted header
+    hash, target header hash, signer digest)."""
     T = _validator_set(b, g, *trusted)
     V = _validator_set(b, g, *target)
     flags = _flags(b, signed)
@@ -369,7 +370,32 @@ def skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, t
     wrap = lambda root: [b.constant(0x0a), b.constant(0x20)] + [x for w in root for x in g.bytes_of_word(w)]
     h_trusted = header_hash_statement(b, g, trusted_header_fields, bound={8: wrap(T["root"])})
     h_target = header_hash_statement(b, g, target_header_fields, bound={7: wrap(V["root"])})
-    return h_trusted, h_target
+    return h_trusted, h_target, _signer_digest(b, g, V["keys"], flags)
+
+
+def _signer_digest(b, g, keys, flags):
+    """Poseidon hash_no_pad over (the 8 big-endian words of each validator's key, its signed flag): 9 elements per validator.  Exposed as public
+    input it BINDS the proof to who was flagged — the hook for the hybrid check (blobstream.verify_signers): the Ed25519 signatures of exactly
+    these validators are verified natively, outside the circuit."""
+    elems = []
+    for kb, f in zip(keys, flags):
+        elems += [g.word_from_bytes(kb[k:k + 4]) for k in range(0, 32, 4)] + [f]
+    return b.hash_no_pad(elems)
+
+
+def signer_digest_host(poseidon_consts, pubkeys, signed):
+    """the same digest on the host (what a consumer recomputes from the keys and flags it was given)"""
+    from . import poseidon_permute_host
+    import numpy as np
+    elems = []
+    for key, sg in zip(pubkeys, signed):
+        elems += list(struct.unpack(">8I", bytes(key))) + [1 if sg else 0]
+    state = np.zeros(12, dtype=np.uint64)
+    for off in range(0, len(elems), 8):
+        chunk = elems[off:off + 8]
+        state[:len(chunk)] = chunk
+        state = poseidon_permute_host(poseidon_consts, state)[0]
+    return [int(v) for v in state[:4]]
 
 
 def step_statement(b, g, trusted_header_fields, target_header_fields, validators, signed):
@@ -380,7 +406,8 @@ def step_statement(b, g, trusted_header_fields, target_header_fields, validators
          the bytes of the hash computed in this circuit, so the chain link is constrained, not asserted,
       3. the flagged validators hold more than 2/3 of the set's power.
     validators = (pubkeys, voting_powers).  The last 38 bytes of the target's field 4 (0x12 0x24 || part-set header) stay opaque witnesses.
-    NOT constrained: the Ed25519 signatures.  Returns (trusted header hash, target header hash): 8 word variables each."""
+    NOT constrained: the Ed25519 signatures — but the proof exposes WHO was flagged (signer digest, 4 words), so a consumer checks exactly those
+    signatures natively.  Returns (trusted header hash, target header hash, signer digest)."""
     V = _validator_set(b, g, *validators)
     flags = _flags(b, signed)
     got = b.constant(0)
@@ -394,16 +421,16 @@ def step_statement(b, g, trusted_header_fields, target_header_fields, validators
         raise ValueError("the target header's last_block_id field is shorter than 0x0a 0x20 || hash")
     block_id = wrap(h_trusted) + [g.byte(b.var(v)) for v in tail]
     h_target = header_hash_statement(b, g, target_header_fields, bound={7: wrap(V["root"]), 4: block_id})
-    return h_trusted, h_target
+    return h_trusted, h_target, _signer_digest(b, g, V["keys"], flags)
 
 
 def step_circuit(prover, trusted_header_fields, target_header_fields, validators, signed):
-    """the circuit of step_statement: public inputs = the trusted header hash then the target header hash (8 words each)"""
+    """the circuit of step_statement: public inputs = the trusted header hash, the target header hash (8 words each), the signer digest (4)"""
     from . import SHA_GATE_WIRES
     b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
     g = Sha256Rows(b)
-    ht, hv = step_statement(b, g, trusted_header_fields, target_header_fields, validators, signed)
-    for w in ht + hv:
+    ht, hv, sd = step_statement(b, g, trusted_header_fields, target_header_fields, validators, signed)
+    for w in ht + hv + sd:
         b.public_input(w)
     to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
     hb_t, hb_v = to_bytes(ht), to_bytes(hv)
@@ -412,13 +439,13 @@ def step_circuit(prover, trusted_header_fields, target_header_fields, validators
 
 
 def skip_circuit(prover, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index):
-    """the circuit of skip_statement: public inputs = the trusted header hash then the target header hash (8 words each).  Returns (circuit,
-    device wires, public values, trusted header hash bytes, target header hash bytes); ValueError when a threshold is not met."""
+    """the circuit of skip_statement: public inputs = the trusted header hash, the target header hash (8 words each), the signer digest (4 words).
+    Returns (circuit, device wires, public values, trusted header hash bytes, target header hash bytes); ValueError when a threshold is not met."""
     from . import SHA_GATE_WIRES
     b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
     g = Sha256Rows(b)
-    ht, hv = skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index)
-    for w in ht + hv:
+    ht, hv, sd = skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index)
+    for w in ht + hv + sd:
         b.public_input(w)
     to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
     hb_t, hb_v = to_bytes(ht), to_bytes(hv)

@@ -148,6 +148,14 @@ def test_sha_rows_hash_bytes_matches_hashlib(length):
         assert bytes(b.value(x) for x in bs) == hashlib.sha256(msg).digest()
 
 
+class _HostPoseidon:
+    """stands in for a Prover on the builder's side: the library's HOST permutation with the small test constants (no GPU)"""
+
+    def poseidon_permute_host(self, states):
+        graft.load_package()
+        return importlib.import_module(graft.PKG_NAME).poseidon_permute_host(poseidon_consts("small"), states)
+
+
 def _validators(rng, n):
     keys = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n)]
     powers = [int(rng.integers(1, 1 << int(rng.integers(1, 49)))) for _ in range(n)]
@@ -268,9 +276,10 @@ def test_skip_statement_on_the_builder():
     gd, rec, bs = _mods()
     rng = np.random.default_rng(88)
     tk, tp, vk, vp, idx, signed, hf_t, hf_v = _skip_case(rng)
-    b = rec.CircuitBuilder(object(), n_wires=144)
+    b = rec.CircuitBuilder(_HostPoseidon(), n_wires=144)
     g = gd.Sha256Rows(b)
-    ht, hv = gd.skip_statement(b, g, hf_t, (tk, tp), hf_v, (vk, vp), signed, idx)
+    ht, hv, sd = gd.skip_statement(b, g, hf_t, (tk, tp), hf_v, (vk, vp), signed, idx)
+    assert [b.value(v) for v in sd] == gd.signer_digest_host(poseidon_consts("small"), vk, signed)
     want_t, want_v = list(hf_t), list(hf_v)
     want_t[8] = b"\x0a\x20" + _validators_hash(bs, tk, tp)
     want_v[7] = b"\x0a\x20" + _validators_hash(bs, vk, vp)
@@ -280,7 +289,7 @@ def test_skip_statement_on_the_builder():
     def fails(**kw):
         args = dict(signed=signed, idx=idx, vk=vk)
         args.update(kw)
-        bb = rec.CircuitBuilder(object(), n_wires=144)
+        bb = rec.CircuitBuilder(_HostPoseidon(), n_wires=144)
         with pytest.raises(ValueError):
             gd.skip_statement(bb, gd.Sha256Rows(bb), hf_t, (tk, tp), hf_v, (args["vk"], vp), args["signed"], args["idx"])
     fails(signed=[True, False, False, False, False])                          # 700 of 2300: not > 2/3 of the target set
@@ -299,9 +308,10 @@ def test_step_statement_links_the_headers():
     rng = np.random.default_rng(90)
     keys, powers = _validators(rng, 4)
     hf_t, hf_v = _header_fields(rng), _header_fields(rng)
-    b = rec.CircuitBuilder(object(), n_wires=144)
+    b = rec.CircuitBuilder(_HostPoseidon(), n_wires=144)
     g = gd.Sha256Rows(b)
-    ht, hv = gd.step_statement(b, g, hf_t, hf_v, (keys, powers), [True] * 4)
+    ht, hv, sd = gd.step_statement(b, g, hf_t, hf_v, (keys, powers), [True] * 4)
+    assert [b.value(v) for v in sd] == gd.signer_digest_host(poseidon_consts("small"), keys, [True] * 4)
     vh = _validators_hash(bs, keys, powers)
     want_t = list(hf_t)
     want_t[8] = b"\x0a\x20" + vh
@@ -381,7 +391,7 @@ def test_skip_circuit_proves(prover, oracle, pkg):
     want_t[8] = b"\x0a\x20" + bs.validator_set_hash(prover, tk, tp)           # the GPU witness kernel's hashes
     want_v[7] = b"\x0a\x20" + bs.validator_set_hash(prover, vk, vp)
     assert hb_t == _tm_tree(want_t) and hb_v == _tm_tree(want_v)
-    assert public == list(struct.unpack(">8I", hb_t)) + list(struct.unpack(">8I", hb_v))
+    assert public == list(struct.unpack(">8I", hb_t)) + list(struct.unpack(">8I", hb_v)) + gd.signer_digest_host((rc, circ, diag), vk, signed)
     proof = ck.prove_(dw, 10, 6, public=public)
     assert ck.verify(proof, 10, 6, public=public), prover.last_reject
     pref.verify_plonk(proof, oracle, pos_consts=(rc, circ, diag), public=public)
@@ -521,3 +531,40 @@ def test_recursion_over_data_commitment_proofs(prover, oracle, pkg):
     with pytest.raises(ValueError):
         rp.prove([leaves[0][0], bad.tobytes()], 8, 4)
     rp.free()
+
+
+@pytest.mark.gpu
+def test_hybrid_commit_check_with_real_signatures(prover, oracle, pkg):
+    """the signature half, checked natively against what the proof exposes: a step circuit over validators whose keys are the RFC 8032 / OpenSSL
+    fixtures' keys; the proof's signer digest binds (keys, flags), and blobstream.verify_signers accepts exactly when every flagged validator's
+    real Ed25519 signature verifies on the GPU kernel — a forged signature, a flipped flag or another key set is refused"""
+    import json
+    gd, rec, bs = _mods()
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ed25519.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["valid"]][:5]
+    keys = [bytes.fromhex(c["pub"]) for c in cases]
+    sigs = [bytes.fromhex(c["sig"]) for c in cases]
+    msgs = [bytes.fromhex(c["msg"]) for c in cases]
+    powers = [500, 400, 300, 200, 100]
+    signed = [True, True, True, True, False]
+    rng = np.random.default_rng(92)
+    ck, dw, public, hb_t, hb_v = gd.step_circuit(prover, _header_fields(rng), _header_fields(rng), (keys, powers), signed)
+    proof = ck.prove_(dw, 10, 6, public=public)
+    assert ck.verify(proof, 10, 6, public=public), prover.last_reject
+    digest = public[16:20]
+    assert digest == gd.signer_digest_host(consts, keys, signed)
+    given = [s_ if f else None for s_, f in zip(sigs, signed)]
+    assert bs.verify_signers(prover, consts, digest, keys, signed, given, msgs)
+    forged = list(given)
+    forged[1] = forged[1][:10] + bytes([forged[1][10] ^ 1]) + forged[1][11:]
+    assert not bs.verify_signers(prover, consts, digest, keys, signed, forged, msgs)
+    assert not bs.verify_signers(prover, consts, digest, keys, [True] * 5, sigs, msgs)          # other flags than the proof was about
+    assert not bs.verify_signers(prover, consts, digest, keys[::-1], signed[::-1], given[::-1], msgs[::-1])
+    missing = list(given)
+    missing[0] = None
+    assert not bs.verify_signers(prover, consts, digest, keys, signed, missing, msgs)
+    dw.free()
+    ck.free()
