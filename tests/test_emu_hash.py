@@ -48,7 +48,7 @@ def test_emulated_poseidon_permutation(emu, oracle, kind):
 
 
 @pytest.mark.parametrize("kind,leaf_len,log_leaves,cap_h", [("small", 135, 7, 2), ("small", 3, 6, 0), ("small", 4, 5, 5),
-                                                            ("small", 8, 6, 1), ("small", 9, 6, 6), ("big", 20, 6, 3)])
+                                                            ("small", 8, 4, 1), ("small", 9, 6, 6), ("big", 20, 6, 3)])
 def test_emulated_merkle(emu, oracle, kind, leaf_len, log_leaves, cap_h):
     c384, (rc, circ, diag) = consts384(kind)
     oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
