@@ -415,9 +415,33 @@ class WitnessProgram:
         delta[1] = 1
         wp = prover.fft(delta)                                                         # w_n^r, r < n
         sigma = prover.field_op("mul", ks[tgt_col], wp[tgt_row])
+        self._sigma = sigma                            # kept for export_raw (a compiled host commits the same circuit from it)
         # the flags follow the rows the circuit has: a selector column that is zero everywhere would still cost its constraints at every LDE point
         return PlonkCircuit(prover, self.consts, sigma, cap_height=cap_height, n_wires=self.W, n_public=len(self.public_vars),
                             poseidon=bool(self.pos_row_ids.size), sha=self.consts.shape[0] == PLONK_NCONST_SHA)
+
+    def export_raw(self, directory, sample_inputs=None, cap_height=1):
+        """the recording as raw little-endian arrays + a text manifest, for a host WITHOUT Python (tests/cpp/host_replay.cpp replays it through the
+        C ABI: glp_plonk_setup_ex, glp_witness_eval_mt, glp_gather_u64, the row fillers, glp_plonk_prove_ex).  Call after setup() (sigma is part
+        of what a host needs).  sample_inputs: an input vector to ship along (inputs.bin)."""
+        import os
+        if getattr(self, "_sigma", None) is None:
+            raise ValueError("export_raw after setup(): sigma is computed there")
+        os.makedirs(directory, exist_ok=True)
+        arrays = {"consts": (self.consts, "<u8"), "sigma": (self._sigma, "<u8"), "prog": (self.prog, "<u8"), "eq_pairs": (self.eq_pairs, "<u8"),
+                  "seg_bounds": (self.seg_bounds if self.seg_bounds is not None else np.zeros(0, dtype=np.uint64), "<u8"),
+                  "cell_index": (self.cell_index, "<u4"), "fixed_values": (self.fixed_values, "<u8"), "pos_rows": (self.pos_row_ids, "<u4"),
+                  "sha_rows": (self.sha_row_ids, "<u4"), "sha_kinds": (self.sha_kinds, "<u4"), "public_vars": (self.public_vars, "<u8")}
+        if sample_inputs is not None:
+            arrays["inputs"] = (np.asarray(sample_inputs, dtype=np.uint64), "<u8")
+        with open(os.path.join(directory, "manifest.txt"), "w") as f:
+            f.write(f"log_n {self.log_n}\nn_wires {self.W}\nn_routed {self.R}\nn_public {len(self.public_vars)}\nn_const {self.consts.shape[0]}\n"
+                    f"n_values {self.n_values}\nn_inputs {self.n_inputs}\ncap_height {cap_height}\n"
+                    f"flags {(1 if self.pos_row_ids.size else 0) | (2 if self.consts.shape[0] == PLONK_NCONST_SHA else 0)}\n")
+            for name, (arr, dt) in arrays.items():
+                a = np.ascontiguousarray(arr).astype(dt)
+                a.tofile(os.path.join(directory, name + ".bin"))
+                f.write(f"array {name} {a.size}\n")
 
     def evaluate(self, poseidon_consts, inputs, threads=None):
         """every variable's value for new inputs (glp_witness_eval_mt: the recorded segments on `threads` host threads, default all cores);

@@ -2,8 +2,13 @@
 C ABI on the GPU — the shape of the Rust/C++ integration INTEGRATION.md describes."""
 import os
 import subprocess
+import sys
 
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import __graft_entry__ as graft  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,3 +33,40 @@ def test_cpp_host_mapreduce_path(pkg, tmp_path):
     """circuit setup, leaf proofs with public inputs, RCCL exchange, statement-bound verification, verdict all-reduce, digests — through the
     C ABI only, from a compiled host: the MapReduce path a Rust host would run"""
     _build_and_run(pkg, tmp_path, "host_mapreduce")
+
+
+def test_cpp_host_replays_a_recorded_circuit(pkg, prover, tmp_path):
+    """Python as the offline circuit compiler only: a DataCommitment leaf (SHA rows + Poseidon rows, 2 blocks) is recorded and exported as raw
+    arrays; a g++-compiled host commits it, generates the witness for the shipped inputs (threads + device placement + row fillers), proves and
+    verifies — C ABI only — and arrives at the key and public inputs the Python side computes"""
+    import hashlib
+    import importlib
+    import struct
+    import numpy as np
+    from conftest import poseidon_consts
+    dm = importlib.import_module(graft.PKG_NAME + ".data_commitment_mr")
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    mr = dm.DataCommitmentMapReduce(prover, consts, leaf_blocks=2, fan_in=2, num_queries=10, pow_bits=6)
+    mr._record_leaf()
+    rng = np.random.default_rng(5)
+    hs = [77, 78]
+    rs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in hs]
+    inputs = [w for h, r in zip(hs, rs) for w in dm.tuple_words(h, r)]
+    out_dir = tmp_path / "rec"
+    mr.leaf_program.export_raw(str(out_dir), sample_inputs=inputs)
+    np.concatenate([np.asarray(a, dtype=np.uint64) for a in consts]).astype("<u8").tofile(str(tmp_path / "pc.bin"))
+    exe = tmp_path / "host_replay"
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_replay.cpp"),
+                    "-o", str(exe), "-L", libdir, "-lglprover", "-pthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), str(out_dir), str(tmp_path / "pc.bin")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout
+    lines = dict(ln.split(" ", 1) for ln in r.stdout.strip().splitlines() if " " in ln)
+    assert int(lines["key0"]) == int(mr.leaf_circuit.cap()[0])
+    public = [int(v) for v in lines["public"].split()]
+    lvl = [hashlib.sha256(b"\x00" + int(h).to_bytes(32, "big") + rr).digest() for h, rr in zip(hs, rs)]
+    root = hashlib.sha256(b"\x01" + lvl[0] + lvl[1]).digest()
+    assert public[:8] == list(struct.unpack(">8I", root)) and public[8:] == dm.tuples_digest(consts, hs, rs, 2)
+    assert "out-of-range input -> -7" in r.stdout
+    mr.free()
