@@ -434,6 +434,14 @@ class WitnessProgram:
                   "sha_rows": (self.sha_row_ids, "<u4"), "sha_kinds": (self.sha_kinds, "<u4"), "public_vars": (self.public_vars, "<u8")}
         if sample_inputs is not None:
             arrays["inputs"] = (np.asarray(sample_inputs, dtype=np.uint64), "<u8")
+        if self.input_tags is not None and self.n_inputs:
+            # programs whose inputs are words of byte strings (the proofs a verifier circuit consumes): input i = word tags[i][1] of string tags[i][0];
+            # plus the facts checked outside the circuit: (string, word, value) constants, (string, word, variable) copies, query-index bit lists
+            arrays["input_tags"] = (self.input_tags, "<u8")
+            arrays["wc_const"] = (self.wc_const, "<u8")
+            arrays["wc_var"] = (self.wc_var, "<u8")
+            arrays["wc_bits"] = (self.wc_bits, "<u8")
+            arrays["wc_bit_vars"] = (self.wc_bit_vars, "<u8")
         with open(os.path.join(directory, "manifest.txt"), "w") as f:
             f.write(f"log_n {self.log_n}\nn_wires {self.W}\nn_routed {self.R}\nn_public {len(self.public_vars)}\nn_const {self.consts.shape[0]}\n"
                     f"n_values {self.n_values}\nn_inputs {self.n_inputs}\ncap_height {cap_height}\n"

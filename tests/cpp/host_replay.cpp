@@ -2,7 +2,9 @@
 // a compiled host through the C ABI only (g++, no hipcc, no Python, no torch): what a Rust prover process does at proving time.
 //   commit the circuit (glp_plonk_setup_ex)  ->  witness: glp_witness_eval_mt on host threads, upload the variables, glp_gather_u64 with the
 //   circuit's cell map, glp_poseidon_gate_fill_rows / glp_sha_gate_fill_rows  ->  glp_plonk_prove_ex  ->  glp_plonk_verify_ex
-// usage: host_replay <dir> <poseidon constants: 384 u64 little-endian>   prints the key's first word, the public inputs and "OK".
+// usage: host_replay <dir> <poseidon constants: 384 u64 little-endian> [proof files...]   prints the key's first word, the public inputs and "OK".
+// With proof files (and no inputs.bin) the recording is a VERIFIER circuit: its inputs are picked from the proofs by the recorded tags — a
+// recursion node proved by a compiled host.
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -52,6 +54,29 @@ int main(int argc, char** argv) {
     auto sha_kinds = load<uint32_t>(dir, "sha_kinds", sizes["sha_kinds"]);
     auto pub_vars = load<uint64_t>(dir, "public_vars", sizes["public_vars"]);
     auto inputs = load<uint64_t>(dir, "inputs", sizes["inputs"]);
+    if (inputs.empty() && sizes.count("input_tags")) {
+        // a verifier circuit: the inputs are words of the proofs given on the command line (argv[3..]), picked by the recorded tags, after the
+        // recorded facts about the other words (statement shape, the child circuit's key) have been checked
+        auto tags = load<uint64_t>(dir, "input_tags", sizes["input_tags"]);
+        auto wcc = load<uint64_t>(dir, "wc_const", sizes["wc_const"]);
+        std::vector<std::vector<uint64_t>> proofs;
+        for (int k = 3; k < argc; k++) {
+            std::ifstream f(argv[k], std::ios::binary | std::ios::ate);
+            const size_t bytes = (size_t)f.tellg();
+            f.seekg(0);
+            std::vector<uint64_t> w(bytes / 8);
+            f.read((char*)w.data(), (std::streamsize)(w.size() * 8));
+            proofs.push_back(std::move(w));
+        }
+        auto word = [&](uint64_t str, uint64_t pos, uint64_t& out) { if (str >= proofs.size() || pos >= proofs[str].size()) return false; out = proofs[str][pos]; return true; };
+        for (size_t i = 0; i + 2 < wcc.size() + 1 && i < wcc.size(); i += 3) {
+            uint64_t v;
+            if (!word(wcc[i], wcc[i + 1], v) || v != wcc[i + 2]) { std::printf("FAIL: proof %llu is not what this circuit was built for (word %llu)\n", (unsigned long long)wcc[i], (unsigned long long)wcc[i + 1]); return 1; }
+        }
+        inputs.resize(tags.size() / 2);
+        for (size_t i = 0; i < inputs.size(); i++)
+            if (!word(tags[2 * i], tags[2 * i + 1], inputs[i])) { std::printf("FAIL: a proof is shorter than the circuit expects\n"); return 1; }
+    }
     std::vector<uint64_t> pc(384);
     { std::ifstream f(argv[2], std::ios::binary); if (!f.read((char*)pc.data(), 384 * 8)) { std::printf("FAIL: constants\n"); return 1; } }
     if (inputs.size() != n_inputs || cell.size() != (size_t)W * n || sigma.size() != (size_t)R * n || consts.size() != meta["n_const"] * n) {
@@ -119,7 +144,7 @@ int main(int argc, char** argv) {
         if (glp_plonk_verify_ex(ctx, proof, len, key.data(), key.size(), other.data(), n_pub, 10, 6) != GLP_E_REJECT) { std::printf("FAIL: wrong statement accepted\n"); return 1; }
     }
     // a witness that breaks a row: an input outside its range is refused by the evaluator
-    if (!inputs.empty()) {
+    if (!inputs.empty() && argc == 3) {
         std::vector<uint64_t> bad_in = inputs;
         bad_in[0] = 1ull << 40;
         std::vector<uint64_t> v2(n_values, 0);

@@ -70,3 +70,51 @@ def test_cpp_host_replays_a_recorded_circuit(pkg, prover, tmp_path):
     assert public[:8] == list(struct.unpack(">8I", root)) and public[8:] == dm.tuples_digest(consts, hs, rs, 2)
     assert "out-of-range input -> -7" in r.stdout
     mr.free()
+
+
+def test_cpp_host_proves_a_recursion_node(pkg, prover, tmp_path):
+    """a recursion node from a compiled host: the verifier circuit of two leaf proofs is recorded and exported by Python; the g++ host reads the two
+    PROOF FILES, checks the recorded facts about them, builds the inputs from the recorded tags, evaluates the verifier's witness on threads,
+    proves and verifies — and its public inputs are the leaf digests and their root, as the Python RecursionProgram computes them"""
+    import importlib
+    import numpy as np
+    import bench
+    from conftest import poseidon_consts
+    vc = importlib.import_module(graft.PKG_NAME + ".verifier_circuit")
+    rec = importlib.import_module(graft.PKG_NAME + ".recursion")
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    c, s_, w = bench.synthetic_circuit(prover, 9, 16)
+    ck = pkg.PlonkCircuit(prover, c, s_)
+    dw = prover.to_device(w)
+    proofs = [ck.prove_(dw, 6, 4) for _ in range(2)]
+    rp = vc.RecursionProgram(prover, proofs, ck.cap(), 6, 4, 16, consts)
+    _, want_public = rp.prove(proofs, 10, 6)
+    out_dir = tmp_path / "node"
+    rp.program.export_raw(str(out_dir))
+    np.concatenate([np.asarray(a, dtype=np.uint64) for a in consts]).astype("<u8").tofile(str(tmp_path / "pc.bin"))
+    files = []
+    for k, p in enumerate(proofs):
+        f = tmp_path / f"proof_{k}.bin"
+        f.write_bytes(p)
+        files.append(str(f))
+    exe = tmp_path / "host_replay"
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_replay.cpp"),
+                    "-o", str(exe), "-L", libdir, "-lglprover", "-pthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), str(out_dir), str(tmp_path / "pc.bin")] + files, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout
+    lines = dict(ln.split(" ", 1) for ln in r.stdout.strip().splitlines() if " " in ln)
+    assert int(lines["key0"]) == int(rp.key()[0]) and [int(v) for v in lines["public"].split()] == want_public
+    digests = [prover.proof_digest(p) for p in proofs]
+    assert want_public == [v for d in digests for v in d] + rec.merkle_root_host(prover, digests)
+    # a tampered leaf proof: the evaluator refuses (a copy constraint of the verifier circuit fails) and the host reports it
+    bad = np.frombuffer(proofs[1], dtype="<u8").copy()
+    bad[len(bad) // 2] ^= np.uint64(1)
+    (tmp_path / "bad.bin").write_bytes(bad.tobytes())
+    r2 = subprocess.run([str(exe), str(out_dir), str(tmp_path / "pc.bin"), files[0], str(tmp_path / "bad.bin")], stdout=subprocess.PIPE,
+                        stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r2.returncode != 0 and "FAIL" in r2.stdout
+    rp.free()
+    dw.free()
+    ck.free()
