@@ -60,6 +60,7 @@ class CircuitShape(ctypes.Structure):
 PLONK_NCONST = 6                 # constant columns: q_arith, c0, c1, c2, q_pi, q_pos
 PLONK_NCONST_SHA = 10            # ... + q_she, q_sha, q_shw, q_add for circuits with SHA-256 rows
 CIRCUIT_SHA_GATES = 2
+CIRCUIT_EXT_GATE = 4                # one more constant column, q_ext (last): rows whose 8-wire chunks are extension multiply-adds
 SHA_GATE_WIRES = 144
 SHA_ROW_E, SHA_ROW_A, SHA_ROW_W, SHA_ROW_ADD = 0, 1, 2, 3
 CIRCUIT_POSEIDON_GATE = 1
@@ -845,19 +846,20 @@ class PlonkCircuit:
       consts: [6][n] = (q_arith, c0, c1, c2, q_pi, q_pos) row values — or the round-1 form [3][n] = (q, c0, c1)
       sigmas: [n_routed][n];  n_wires: total wire columns (default: all routed);  n_public: rows 0..n_public-1 expose wire 0
       poseidon: q_pos rows carry a permutation (needs n_wires >= 130, n_routed >= 24)
-      sha: SHA-256 rows (consts [10][n]: + q_she, q_sha, q_shw, q_add; n_wires >= 144, n_routed >= 16)"""
+      sha: SHA-256 rows (consts [10][n]: + q_she, q_sha, q_shw, q_add; n_wires >= 144, n_routed >= 16)
+      ext: extension-arithmetic rows (one more column, q_ext, LAST: consts [7][n] or [11][n])"""
 
-    def __init__(self, prover, consts, sigmas, rate_bits=3, cap_height=4, n_wires=None, n_public=0, poseidon=False, sha=False):
+    def __init__(self, prover, consts, sigmas, rate_bits=3, cap_height=4, n_wires=None, n_public=0, poseidon=False, sha=False, ext=False):
         self.prover = prover
         c = np.ascontiguousarray(consts, dtype=np.uint64)
         s = np.ascontiguousarray(sigmas, dtype=np.uint64)
         self.n_routed, n = s.shape
         self.n_wires = self.n_routed if n_wires is None else int(n_wires)
         self.n_public = int(n_public)
-        self.flags = (CIRCUIT_POSEIDON_GATE if poseidon else 0) | (CIRCUIT_SHA_GATES if sha else 0)
+        self.flags = (CIRCUIT_POSEIDON_GATE if poseidon else 0) | (CIRCUIT_SHA_GATES if sha else 0) | (CIRCUIT_EXT_GATE if ext else 0)
         self.log_n = n.bit_length() - 1
-        nc = PLONK_NCONST_SHA if sha else PLONK_NCONST
-        assert 1 << self.log_n == n and c.shape in ((3, n), (PLONK_NCONST, n), (nc, n))
+        nc = PLONK_NCONST + (4 if sha else 0) + (1 if ext else 0)
+        assert 1 << self.log_n == n and (c.shape == (nc, n) or (not ext and c.shape in ((3, n), (PLONK_NCONST, n))))
         if c.shape[0] < nc:
             c = np.concatenate([c, np.zeros((nc - c.shape[0], n), dtype=np.uint64)])
         dc, ds = prover.to_device(c), prover.to_device(s)

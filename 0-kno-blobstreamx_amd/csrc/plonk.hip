@@ -70,7 +70,7 @@ extern "C" int glp_plonk_setup_ex(glp_ctx* c, const glp_circuit_shape* sh, const
     // Poseidon row degree 8, so the quotient has degree < 8n — 8 chunks, evaluated on the 8n-point coset; a larger blow-up
     // would only make every commitment bigger.  W <= 160 = 20 chunks of wires: what the K7 register budget was sized for.
     if (log_n < 3 || log_n > 24 || n_wires == 0 || n_wires % 8 || n_wires > 160 || R == 0 || R % 8 || R > n_wires || sh->rate_bits != 3 ||
-        sh->cap_height > 12 || sh->n_public > (1u << log_n) || (sh->flags & ~(GLP_CIRCUIT_POSEIDON_GATE | GLP_CIRCUIT_SHA_GATES))) {
+        sh->cap_height > 12 || sh->n_public > (1u << log_n) || (sh->flags & ~(GLP_CIRCUIT_POSEIDON_GATE | GLP_CIRCUIT_SHA_GATES | GLP_CIRCUIT_EXT_GATE))) {
         glp_set_err(c, "glp_plonk_setup: unsupported shape (W %% 8 == 0, W <= 160, routed %% 8 == 0, routed <= W, rate_bits == 3, n_public <= n)");
         return GLP_E_INVALID;
     }
@@ -242,7 +242,8 @@ static int quotient_evals(glp_ctx* c, glp_plonk_circuit* ck, const u64* wires_ld
     int rc = glp_ntt_table(c, (int)log_N, 0, &wN_lo, &wN_hi);
     if (rc) return rc;
     GlpQuotientArgs qa;
-    qa.consts = ck->pre.lde.u(); qa.sigmas = ck->pre.lde.u() + (u64)glp_plonk_n_const(ck->flags) * N; qa.wires = wires_lde; qa.zs = zs_lde; qa.pi = pi_lde;
+    qa.consts = ck->pre.lde.u(); qa.sigmas = ck->pre.lde.u() + (u64)glp_plonk_n_const(ck->flags) * N;
+    qa.q_ext = (ck->flags & GLP_CIRCUIT_EXT_GATE) ? ck->pre.lde.u() + (u64)(glp_plonk_n_const(ck->flags) - 1) * N : nullptr; qa.wires = wires_lde; qa.zs = zs_lde; qa.pi = pi_lde;
     qa.ks = ck->ks.u();
     qa.log_n = log_n; qa.rate_bits = rb; qa.W = ck->W; qa.R = ck->R; qa.n_con = n_con;
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) { qa.beta[t] = beta[t]; qa.gamma[t] = gamma[t]; }

@@ -183,7 +183,22 @@ GL_HD typename O::F glp_arith_gate(typename O::F c0, typename O::F c1, typename 
 #define GLP_SHA_ROW_A 1
 #define GLP_SHA_ROW_W 2
 #define GLP_SHA_ROW_ADD 3
-GL_HD int glp_plonk_n_const(u32 flags) { return (flags & GLP_CIRCUIT_SHA_GATES) ? GLP_PLONK_NCONST_SHA : GLP_PLONK_NCONST; }
+// ---- extension-arithmetic rows (GLP_CIRCUIT_EXT_GATE) ------------------------------------------------------------------------------
+// One more selector column, q_ext (the LAST constant column: index 6, or 10 next to the SHA selectors).  On a q_ext row every chunk of 8 routed
+// wires (x0, x1, y0, y1, z0, z1, w0, w1) is one multiply-add in F_p[X]/(X^2 - 7):  w = x * y + z, i.e.
+//     e0 = x0*y0 + 7*x1*y1 + z0 - w0,      e1 = x0*y1 + x1*y0 + z1 - w1
+// The two values share the chunk's two arithmetic-gate slots of the alpha order (slot = q_arith * gate + q_ext * e: at most one of the selectors
+// is set on a row), so the constraint count does not change.  What an in-circuit verifier mostly does is extension arithmetic: four arithmetic
+// gates (16 wires) per product become one chunk (8 wires).
+#define GLP_CIRCUIT_EXT_GATE 4u
+GL_HD int glp_plonk_n_const(u32 flags) {
+    return GLP_PLONK_NCONST + ((flags & GLP_CIRCUIT_SHA_GATES) ? 4 : 0) + ((flags & GLP_CIRCUIT_EXT_GATE) ? 1 : 0);
+}
+template <class O>
+GL_HD void glp_ext_gate(const typename O::F (&w)[8], typename O::F& e0, typename O::F& e1) {
+    e0 = O::sub(O::add(O::add(O::mul(w[0], w[2]), O::scale(O::mul(w[1], w[3]), 7)), w[4]), w[6]);
+    e1 = O::sub(O::add(O::add(O::mul(w[0], w[3]), O::mul(w[1], w[2])), w[5]), w[7]);
+}
 
 // wire(j) -> F: wire j of the row; q[4] = (q_she, q_sha, q_shw, q_add) at the point; c2 = the row's c2 column; emit receives the 140
 // selector-weighted constraint values in order.

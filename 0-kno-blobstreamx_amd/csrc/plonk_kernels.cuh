@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(256) glp_scan_apply_kernel(const u64* __restri
 // out[t][i] = (sum alpha_t^idx * constraint_idx) / (x^n - 1).
 struct GlpQuotientArgs {
     const u64* consts; const u64* sigmas; const u64* wires; const u64* zs; const u64* pi; const u64* ks;
+    const u64* q_ext;              // [N] the extension-arithmetic selector (GLP_CIRCUIT_EXT_GATE circuits), else null
     u32 log_n; u32 rate_bits; u32 W; u32 R; u32 n_con;
     u64 beta[GLP_PLONK_NCHAL], gamma[GLP_PLONK_NCHAL];
     const u64* alpha_pow;          // [NCHAL][n_con]
@@ -245,6 +246,7 @@ __global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
     // L_1(x) * (Z - 1) / (x^n - 1) = (Z - 1) / (n (x - 1)): the vanishing factor cancels
     const u64 l1_over_zh = gl_mul(a.n_inv, a.inv_xm1[i]);
     const u64 q = a.consts[i], c0 = a.consts[N + i], c1 = a.consts[2 * N + i], c2 = a.consts[3 * N + i], q_pi = a.consts[4 * N + i];
+    const u64 qx = a.q_ext ? a.q_ext[i] : 0ull;
     u64 acc[GLP_PLONK_NCHAL], prev[GLP_PLONK_NCHAL], bx[GLP_PLONK_NCHAL];
     // public inputs (alpha^1)
     const u64 pi_con = gl_sub(gl_mul(q_pi, a.wires[i]), a.pi ? a.pi[i] : 0ull);
@@ -264,8 +266,14 @@ __global__ void __launch_bounds__(256) glp_quotient_kernel(GlpQuotientArgs a) {
             kk[jj] = a.ks[j];
         });
         // the two arithmetic gates of this chunk (shared by both challenges up to alpha)
-        const u64 g0 = gl_mul(q, glp_arith_gate<GlpGateBase>(c0, c1, c2, w[0], w[1], w[2], w[3]));
-        const u64 g1 = gl_mul(q, glp_arith_gate<GlpGateBase>(c0, c1, c2, w[4], w[5], w[6], w[7]));
+        u64 g0 = gl_mul(q, glp_arith_gate<GlpGateBase>(c0, c1, c2, w[0], w[1], w[2], w[3]));
+        u64 g1 = gl_mul(q, glp_arith_gate<GlpGateBase>(c0, c1, c2, w[4], w[5], w[6], w[7]));
+        if (a.q_ext) {                           // wave-uniform: the chunk as one extension multiply-add, in the same two slots
+            u64 e0, e1;
+            glp_ext_gate<GlpGateBase>(w, e0, e1);
+            g0 = gl_add(g0, gl_mul(qx, e0));
+            g1 = gl_add(g1, gl_mul(qx, e1));
+        }
         for (u32 t = 0; t < GLP_PLONK_NCHAL; t++) {
             u64 num = 1, den = 1;
             glp_static_for<0, GLP_PLONK_CHUNK>([&](auto j_) {

@@ -358,7 +358,7 @@ bool make_hasher_from(const u64* rc, const u64* circ, const u64* diag, Hasher& h
 }
 
 // sum_idx alpha_t^idx * C_idx at zeta for challenge t (the constraint list of plonk_kernels.cuh / DESIGN.md §3.6), extension field
-gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 R, bool poseidon, bool sha, const u64* pos_consts, const std::vector<u64>& ks, const u64* beta,
+gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 R, bool poseidon, bool sha, const gl_ext2* q_ext, const u64* pos_consts, const std::vector<u64>& ks, const u64* beta,
                        const u64* gamma, const u64* alpha, const gl_ext2* consts, const gl_ext2* sigmas, const gl_ext2* wires, const gl_ext2* zs,
                        const gl_ext2* z_next, gl_ext2 pi_at_x) {
     typedef GlpGateExt O;
@@ -382,8 +382,15 @@ gl_ext2 constraint_sum(u32 t, gl_ext2 x, gl_ext2 xn, u64 n, u32 R, bool poseidon
         const gl_ext2 nx = cidx + 1 < M ? zs[t * M + 1 + cidx] : z_next[t];
         const gl_ext2 perm = gl_ext_sub(gl_ext_mul(prev, num), gl_ext_mul(nx, den));
         const gl_ext2* w8 = wires + cidx * CHUNK;
-        const gl_ext2 g0 = gl_ext_mul(q, glp_arith_gate<O>(c0, c1, c2, w8[0], w8[1], w8[2], w8[3]));
-        const gl_ext2 g1 = gl_ext_mul(q, glp_arith_gate<O>(c0, c1, c2, w8[4], w8[5], w8[6], w8[7]));
+        gl_ext2 g0 = gl_ext_mul(q, glp_arith_gate<O>(c0, c1, c2, w8[0], w8[1], w8[2], w8[3]));
+        gl_ext2 g1 = gl_ext_mul(q, glp_arith_gate<O>(c0, c1, c2, w8[4], w8[5], w8[6], w8[7]));
+        if (q_ext) {
+            const gl_ext2 ww[8] = {w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7]};
+            gl_ext2 e0, e1;
+            glp_ext_gate<O>(ww, e0, e1);
+            g0 = gl_ext_add(g0, gl_ext_mul(*q_ext, e0));
+            g1 = gl_ext_add(g1, gl_ext_mul(*q_ext, e1));
+        }
         const gl_ext2 cons[3] = {perm, g0, g1};
         for (int i = 0; i < 3; i++) {
             ap = gl_mul(ap, alpha[t]);
@@ -460,7 +467,7 @@ static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, co
     if (!take_obs(8, &hd)) return rj.fail("truncated");
     const u64 tag = hd[0], log_n = hd[1], W = hd[2], R = hd[3], rb = hd[4], cap_h = hd[5], n_pub = hd[6], flags = hd[7];
     if (tag != PLONK_TAG || rb != 3 || W % 8 || W < 8 || W > 160 || R % 8 || R < 8 || R > W || log_n < 3 || log_n > 24 ||
-        n_pub > (1ull << log_n) || (flags & ~(u64)(GLP_CIRCUIT_POSEIDON_GATE | GLP_CIRCUIT_SHA_GATES)))
+        n_pub > (1ull << log_n) || (flags & ~(u64)(GLP_CIRCUIT_POSEIDON_GATE | GLP_CIRCUIT_SHA_GATES | GLP_CIRCUIT_EXT_GATE)))
         return rj.fail("bad plonk header");
     const bool poseidon = (flags & GLP_CIRCUIT_POSEIDON_GATE) != 0, sha = (flags & GLP_CIRCUIT_SHA_GATES) != 0;
     if (poseidon && (W < GLP_POS_GATE_WIRES || R < 24)) return rj.fail("bad plonk header");
@@ -521,7 +528,8 @@ static int plonk_verify_entry(Reject rj, const Hasher& h, glp_challenger& ch, co
     gl_ext2 z_next[NCHAL];
     for (u32 t = 0; t < NCHAL; t++) z_next[t] = zs_next[t * M];
     for (u32 t = 0; t < NCHAL; t++) {
-        const gl_ext2 lhs = constraint_sum(t, fi.zeta, zn, n, (u32)R, poseidon, sha, h.consts.data(), ks, beta, gamma, alpha, pre, pre + n_const,
+        const gl_ext2 lhs = constraint_sum(t, fi.zeta, zn, n, (u32)R, poseidon, sha, (flags & GLP_CIRCUIT_EXT_GATE) ? pre + n_const - 1 : nullptr, h.consts.data(), ks, beta, gamma, alpha, pre,
+                                           pre + n_const,
                                            wires, zs, z_next, pi_z);
         gl_ext2 tz{0, 0}, zp{1, 0};
         for (u32 cc = 0; cc < (1u << rb); cc++) {

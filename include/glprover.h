@@ -201,6 +201,10 @@ void glp_free_host(void* p);
  *                           and equations: csrc/plonk_gates.h */
 #define GLP_PLONK_NCONST_SHA 10
 #define GLP_CIRCUIT_SHA_GATES 2u
+/*   extension rows (flag)   one more constant column, q_ext, LAST (index 6, or 10 with the SHA selectors): on a q_ext row every chunk of 8 routed
+ *                           wires (x0, x1, y0, y1, z0, z1, w0, w1) is w = x * y + z in F_p[X]/(X^2 - 7); no further constraints (the two
+ *                           values share the chunk's arithmetic-gate slots).  d_const_vals then has glp n_const = 6 + 4 (SHA) + 1 rows */
+#define GLP_CIRCUIT_EXT_GATE 4u
 #define GLP_SHA_GATE_WIRES 144
 #define GLP_SHA_ROW_E 0
 #define GLP_SHA_ROW_A 1

@@ -319,6 +319,7 @@ extern "C" int emu_plonk_quotient(const u64* consts, const u64* sigmas, const u6
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) { u64 x = 1; for (u32 k = 0; k < n_con; k++) { apow[(size_t)t * n_con + k] = x; x = gl_mul(x, alpha[t]); } }
     GlpQuotientArgs qa;
     qa.consts = consts; qa.sigmas = sigmas; qa.wires = wires; qa.zs = zs; qa.pi = pi; qa.ks = ks.data();
+    qa.q_ext = (flags & GLP_CIRCUIT_EXT_GATE) ? consts + (u64)(glp_plonk_n_const(flags) - 1) * N : nullptr;
     qa.log_n = log_n; qa.rate_bits = rb; qa.W = W; qa.R = R; qa.n_con = n_con;
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) { qa.beta[t] = beta[t]; qa.gamma[t] = gamma[t]; }
     qa.alpha_pow = apow.data(); qa.pos_consts = pos_consts; qa.w_lo = lo.data(); qa.w_hi = hip; qa.shift = 7;

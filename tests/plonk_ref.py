@@ -24,8 +24,11 @@ SHA_E, SHA_A, SHA_W, SHA_ADD = 0, 1, 2, 3
 M32 = 0xFFFFFFFF
 
 
+FLAG_EXT = 4                   # one more constant column, q_ext, LAST: rows whose 8-wire chunks are multiply-adds in F_p[X]/(X^2 - 7)
+
+
 def n_const(flags):
-    return NCONST_SHA if flags & FLAG_SHA else NCONST
+    return NCONST + (4 if flags & FLAG_SHA else 0) + (1 if flags & FLAG_EXT else 0)
 
 
 def ks_of(W):
@@ -236,7 +239,8 @@ def int_consts(consts):
 
 
 # ---- circuit generator -------------------------------------------------------------------------------------------------------
-def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, poseidon_rows=(), consts=None, public_values=None, sha_rows=()):
+def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, poseidon_rows=(), consts=None, public_values=None, sha_rows=(),
+                  ext_rows=()):
     """random satisfiable instance.  Returns a dict: consts [6][n], sigmas [R][n], wires [W][n] (uint64), public (list of ints),
     shape fields.  poseidon_rows: row indices that carry a permutation (needs W >= 130, R >= 24 and the Poseidon constants);
     n_public: rows 0..n_public-1 expose wire 0 as a public input (public_values: what those cells must hold; default random)."""
@@ -245,12 +249,13 @@ def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, posei
     G = R // 4
     pos = set(int(r) for r in poseidon_rows)
     sha = {int(r): int(rng.integers(0, 4)) for r in sha_rows}          # row -> kind
-    assert not (pos & set(sha)) and (not sha or (W >= SHA_WIRES and R >= 16))
+    ext = set(int(r) for r in ext_rows)
+    assert not (pos & set(sha)) and (not sha or (W >= SHA_WIRES and R >= 16)) and not (ext & (pos | set(sha)))
     if pos:
         assert W >= POS_WIRES and R >= 24 and consts is not None
         consts = int_consts(consts)
     rnd = lambda: int(rng.integers(0, 1 << 62)) * 4 % P
-    q = [0 if (i in pos or i in sha) else (1 if rng.random() < 0.8 else 0) for i in range(n)]
+    q = [0 if (i in pos or i in sha or i in ext) else (1 if rng.random() < 0.8 else 0) for i in range(n)]
     c0 = [rnd() for _ in range(n)]
     c1 = [rnd() for _ in range(n)]
     c2 = [rnd() if rng.random() < 0.5 else 0 for _ in range(n)]
@@ -290,6 +295,18 @@ def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, posei
 
     r32 = lambda: int(rng.integers(0, 1 << 32))
     for i in range(n):
+        if i in ext:
+            for c in range(R // 8):
+                for k in range(6):              # x0, x1, y0, y1, z0, z1: free cells or copies
+                    fresh_or_copy(8 * c + k, i)
+                x0, x1, y0, y1, z0, z1 = (wires[8 * c + k][i] for k in range(6))
+                wires[8 * c + 6][i] = (x0 * y0 + 7 * x1 * y1 + z0) % P
+                wires[8 * c + 7][i] = (x0 * y1 + x1 * y0 + z1) % P
+                cells.append((8 * c + 6, i))
+                cells.append((8 * c + 7, i))
+            for j in range(R, W):
+                wires[j][i] = rnd()
+            continue
         if i in sha:
             kind = sha[i]
             if kind == SHA_E:
@@ -342,8 +359,10 @@ def build_circuit(rng, log_n, W, copy_prob=0.5, n_routed=None, n_public=0, posei
             jj, ii = members[(a + 1) % len(members)]
             sigma[j][i] = ks[jj] * wp[ii] % P
     to_np = lambda rows: np.array(rows, dtype=np.uint64)
-    return {"log_n": log_n, "W": W, "R": R, "n_public": n_public, "flags": (FLAG_POSEIDON if pos else 0) | (FLAG_SHA if sha else 0),
-            "consts": to_np([q, c0, c1, c2, q_pi, q_pos] + (q_sha if sha else [])), "sigmas": to_np(sigma), "wires": to_np(wires),
+    q_ext = [1 if i in ext else 0 for i in range(n)]
+    return {"log_n": log_n, "W": W, "R": R, "n_public": n_public,
+            "flags": (FLAG_POSEIDON if pos else 0) | (FLAG_SHA if sha else 0) | (FLAG_EXT if ext else 0),
+            "consts": to_np([q, c0, c1, c2, q_pi, q_pos] + (q_sha if sha else []) + ([q_ext] if ext else [])), "sigmas": to_np(sigma), "wires": to_np(wires),
             "public": [wires[0][i] for i in range(n_public)], "pos_consts": consts}
 
 
@@ -408,6 +427,7 @@ def constraint_sum(t, x, n, R, ks, beta, gamma, alpha, consts, sigmas, wires, zs
     inv = fv.einv if ext else (lambda v: pow(v, P - 2, P))
     l1 = F.mul(F.sub(xn, one), inv(F.scale(F.sub(x, one), n % P)))
     q, c0, c1, c2, q_pi, q_pos = consts[:6]
+    q_ext = consts[-1] if len(consts) in (NCONST + 1, NCONST_SHA + 1) else None
     acc = F.mul(l1, F.sub(zs[t * M], one))
     ap = alpha[t]
     acc = F.add(acc, F.scale(F.sub(F.mul(q_pi, wires[0]), pi_at_x), ap))
@@ -423,7 +443,13 @@ def constraint_sum(t, x, n, R, ks, beta, gamma, alpha, consts, sigmas, wires, zs
         perm = F.sub(F.mul(prev, num), F.mul(nxt, den))
         w8 = wires[c * CHUNK:(c + 1) * CHUNK]
         gate = lambda xx, yy, zz, ww: F.mul(q, F.sub(F.add(F.add(F.mul(c0, F.mul(xx, yy)), F.mul(c1, zz)), c2), ww))
-        for con in (perm, gate(*w8[0:4]), gate(*w8[4:8])):
+        g0, g1 = gate(*w8[0:4]), gate(*w8[4:8])
+        if q_ext is not None:                  # the chunk as w = x * y + z in the quadratic extension, in the same two slots
+            x0, x1, y0, y1, z0, z1, w0, w1 = w8
+            e0 = F.sub(F.add(F.add(F.mul(x0, y0), F.scale(F.mul(x1, y1), 7)), z0), w0)
+            e1 = F.sub(F.add(F.add(F.mul(x0, y1), F.mul(x1, y0)), z1), w1)
+            g0, g1 = F.add(g0, F.mul(q_ext, e0)), F.add(g1, F.mul(q_ext, e1))
+        for con in (perm, g0, g1):
             ap = ap * alpha[t] % P
             acc = F.add(acc, F.scale(con, ap))
         prev = nxt
@@ -433,7 +459,7 @@ def constraint_sum(t, x, n, R, ks, beta, gamma, alpha, consts, sigmas, wires, zs
             ap = ap * alpha[t] % P
             pacc = F.add(pacc, F.scale(con, ap))
         acc = F.add(acc, F.mul(q_pos, pacc))
-    if len(consts) == NCONST_SHA:
+    if len(consts) >= NCONST_SHA:
         for con in sha_constraints(F, wires, consts[6:10], c2):
             ap = ap * alpha[t] % P
             acc = F.add(acc, F.scale(con, ap))
@@ -487,7 +513,7 @@ def verify_plonk(proof_bytes, oracle, pos_consts=None, public=None):
 
     tag, log_n, W, R, rb, cap_h, n_pub, flags = take(8)
     if tag != TAG or rb != 3 or W % 8 or not (8 <= W <= 160) or R % 8 or not (8 <= R <= W) or not (3 <= log_n <= 24) or n_pub > (1 << log_n) \
-            or flags & ~(FLAG_POSEIDON | FLAG_SHA):
+            or flags & ~(FLAG_POSEIDON | FLAG_SHA | FLAG_EXT):
         raise fv.VerifyError("bad plonk header")
     if flags & FLAG_SHA and (W < SHA_WIRES or R < 16):
         raise fv.VerifyError("SHA-row circuit: bad shape")

@@ -208,3 +208,27 @@ def test_quotient_with_sha_rows(emu, oracle, log_n, W, R, n_public, pos_rows, sh
         assert [[int(v) for v in r] for r in g2] == w2
         with pytest.raises(AssertionError):
             _assert_polynomial_quotient(emu, oracle, g2, log_n)
+
+
+@pytest.mark.parametrize("log_n,W,R,pos_rows,sha_rows,ext_rows", [(3, 16, 16, (), (), (1, 2, 5)), (4, 144, 24, (1,), (0, 2, 3), (4, 5, 6, 12))])
+def test_quotient_with_ext_rows(emu, oracle, log_n, W, R, pos_rows, sha_rows, ext_rows):
+    """extension-arithmetic rows under emulation: K7 equals the restatement, the quotient is a polynomial, a wrong product component is not"""
+    consts = poseidon_consts("small")
+    rng = np.random.default_rng(17 * log_n + W)
+    beta = [int(v) for v in rand_field(rng, 2)]
+    gamma = [int(v) for v in rand_field(rng, 2)]
+    alpha = [int(v) for v in rand_field(rng, 2)]
+    for copy_prob in (0.5, 0.0):
+        circ = pr.build_circuit(rng, log_n, W, copy_prob=copy_prob, n_routed=R, n_public=1, poseidon_rows=pos_rows, consts=consts, sha_rows=sha_rows,
+                                ext_rows=ext_rows)
+        got, want = _emu_quotient(emu, oracle, circ, beta, gamma, alpha)
+        assert [[int(v) for v in r] for r in got] == want
+        _assert_polynomial_quotient(emu, oracle, got, log_n)
+    for wire in (6, 7):                         # on the copy-free circuit: only the row's own equations notice
+        c2 = dict(circ)
+        c2["wires"] = circ["wires"].copy()
+        c2["wires"][wire, ext_rows[0]] ^= np.uint64(1)
+        g2, w2 = _emu_quotient(emu, oracle, c2, beta, gamma, alpha)
+        assert [[int(v) for v in r] for r in g2] == w2
+        with pytest.raises(AssertionError):
+            _assert_polynomial_quotient(emu, oracle, g2, log_n)
