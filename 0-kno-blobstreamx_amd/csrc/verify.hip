@@ -627,6 +627,7 @@ extern "C" int glp_poseidon_permute_host(const uint64_t* h_rc, const uint64_t* h
 //   6 POSEIDON o0..o11 i0..i11  outputs = permutation(inputs)
 //   7 SHA_E T1 e_new e f g h d w K    8 SHA_A a_new a b c T1    9 SHA_W w_new w16 w15 w7 w2    10 ADD32 s x y      (the SHA rows of plonk_gates.h;
 //   11 BITS w x shift bits   w = (x >> shift) mod 2^bits     12 POSEIDON_SWAP o0..o11 i0..i11 s   the Poseidon row with its swap bit
+//   13 EXTMULADD w0 w1 x0 x1 y0 y1 z0 z1   w = x * y + z in the quadratic extension (the extension-arithmetic row)
 //     an input that is not a 32-bit word -> GLP_E_REJECT with *first_bad = (size_t)-1: no witness satisfies the row)
 // eq_pairs: 2*n_eq variable indices that must hold equal values (the circuit's copy constraints between DIFFERENT variables): the first
 // violated pair is reported through *first_bad and the call returns GLP_E_REJECT — the witness does not satisfy the circuit (e.g. the
@@ -752,6 +753,17 @@ static int witness_run(const Hasher& h, const u64* prog, size_t pc, size_t end, 
                 h.permute(st);
                 for (int i = 0; i < 12; i++) { if (!wr(a[i])) return GLP_E_INVALID; values[a[i]] = st[i]; }
                 pc += 26;
+                break;
+            }
+            case 13: {  // EXTMULADD  w0 w1 | x0 x1 y0 y1 z0 z1:  w = x * y + z in F_p[X]/(X^2 - 7)
+                if (pc + 9 > end) return GLP_E_INVALID;
+                for (int i = 0; i < 8; i++) if (!ok(a[i])) return GLP_E_INVALID;
+                for (int i = 2; i < 8; i++) if (!rd(a[i])) return GLP_E_INVALID;
+                const gl_ext2 x{values[a[2]], values[a[3]]}, y{values[a[4]], values[a[5]]}, z{values[a[6]], values[a[7]]};
+                const gl_ext2 w = gl_ext_add(gl_ext_mul(x, y), z);
+                if (!wr(a[0]) || !wr(a[1])) return GLP_E_INVALID;
+                values[a[0]] = w.a; values[a[1]] = w.b;
+                pc += 9;
                 break;
             }
             case 11: {  // BITS  w | x shift bits:  w = (x >> shift) mod 2^bits

@@ -22,7 +22,7 @@ from . import (CIRCUIT_POSEIDON_GATE, P, PLONK_NCONST, PLONK_NCONST_SHA, POS_GAT
 class CircuitBuilder:
     """variables are integer handles; every gate is added with its witness value computed on the spot (big-int arithmetic)"""
 
-    def __init__(self, prover, n_wires=136, n_routed=80):
+    def __init__(self, prover, n_wires=136, n_routed=80, ext_gate=False):
         assert n_routed % 8 == 0 and n_wires % 8 == 0 and 24 <= n_routed <= n_wires and n_wires >= POS_GATE_WIRES
         self.prover, self.W, self.R = prover, n_wires, n_routed
         self.G = n_routed // 4
@@ -31,6 +31,8 @@ class CircuitBuilder:
         self.arith_rows = {}             # (c0, c1, c2) -> list of rows, a row = list of (x, y, z, w) variable tuples
         self.pos_rows = []               # (in vars[12], out vars[12])
         self.sha_rows = []               # (kind, [12 variables or None], K): SHA-256 rows (csrc/plonk_gates.h); needs n_wires >= 144
+        self.ext_gate = bool(ext_gate)   # extension-arithmetic rows allowed (one more constant column: a property of the circuit)
+        self.ext_rows = [[]]             # rows of (x0, x1, y0, y1, z0, z1, w0, w1) tuples, n_routed / 8 per row
         self._add_open = None            # the ADD row still taking additions (4 per row)
         self.public = []
         self._consts = {}
@@ -232,6 +234,19 @@ class CircuitBuilder:
         self.prog += (11, v, x, shift, bits)
         return v
 
+    def ext_mul_add(self, x, y, z):
+        """w = x * y + z in F_p[X]/(X^2 - 7) for pairs of variables: ONE chunk of an extension-arithmetic row (8 wires) instead of six
+        arithmetic gates.  Needs ext_gate=True."""
+        assert self.ext_gate, "this builder was made without extension rows"
+        x0, x1, y0, y1, z0, z1 = (self.values[v] for v in (*x, *y, *z))
+        w0 = self._new(x0 * y0 + 7 * x1 * y1 + z0)
+        w1 = self._new(x0 * y1 + x1 * y0 + z1)
+        self.prog += (13, w0, w1, *x, *y, *z)
+        if len(self.ext_rows[-1]) == self.R // 8:
+            self.ext_rows.append([])
+        self.ext_rows[-1].append((*x, *y, *z, w0, w1))
+        return (w0, w1)
+
     def two_to_one(self, left4, right4):
         """PoseidonHash::two_to_one: permute(left || right || 0 0 0 0)[0..4)"""
         zero = self.constant(0)
@@ -281,10 +296,12 @@ class WitnessProgram:
         W, R, G = b.W, b.R, b.G
         self.W, self.R = W, R
         arith = [(key, row) for key, rows in sorted(b.arith_rows.items()) for row in rows if row]
-        n_rows = len(b.public) + len(b.pos_rows) + len(b.sha_rows) + len(arith)
+        ext_rows = [r for r in b.ext_rows if r]
+        self.has_sha, self.has_ext = bool(b.sha_rows), bool(b.ext_gate)
+        n_rows = len(b.public) + len(b.pos_rows) + len(b.sha_rows) + len(ext_rows) + len(arith)
         self.log_n = max(3, (max(n_rows, 1) - 1).bit_length())
         n = 1 << self.log_n
-        consts = np.zeros((PLONK_NCONST_SHA if b.sha_rows else PLONK_NCONST, n), dtype=np.uint64)
+        consts = np.zeros((PLONK_NCONST + (4 if self.has_sha else 0) + (1 if self.has_ext else 0), n), dtype=np.uint64)
         fixed = []                                   # (wire, row, value): cells of unused gate slots that must hold c2
         cj, ci, cv = [], [], []                      # placed cells: wire, row, variable
         i = 0
@@ -311,6 +328,12 @@ class WitnessProgram:
             sha_kinds.append(kind)
             i += 1
         self.sha_row_ids, self.sha_kinds = np.array(sha_ids, dtype=np.uint32), np.array(sha_kinds, dtype=np.uint32)
+        for row in ext_rows:                                             # q_ext is the LAST constant column
+            consts[-1, i] = 1
+            for c, op in enumerate(row):
+                for k, v in enumerate(op):
+                    cj.append(8 * c + k); ci.append(i); cv.append(v)
+            i += 1
         for (c0, c1, c2), row in arith:
             consts[0, i], consts[1, i], consts[2, i], consts[3, i] = 1, c0, c1, c2
             for g, slot in enumerate(row):
@@ -347,12 +370,12 @@ class WitnessProgram:
         self.wc_bits = np.array([(c[1][0], c[1][1], len(c[2])) for c in bits], dtype=np.int64).reshape(-1, 3)
         self.wc_bit_vars = np.array([v for c in bits for v in c[2]], dtype=np.int64)
         self.stats = {"rows": n, "poseidon_rows": len(b.pos_rows), "arith_gates": sum(len(r) for _, r in arith), "variables": self.n_values,
-                      "inputs": self.n_inputs, "sha_rows": len(b.sha_rows), "rows_used": n_rows}
+                      "inputs": self.n_inputs, "sha_rows": len(b.sha_rows), "rows_used": n_rows, "ext_rows": len(ext_rows)}
         self._finish()
 
     _SAVED = ("consts", "cj", "ci", "cv", "fixed", "pos_row_ids", "sha_row_ids", "sha_kinds", "public_vars", "roots", "prog", "eq_pairs", "wc_const", "wc_var",
               "wc_bits", "wc_bit_vars")
-    _STATS = ("rows", "poseidon_rows", "arith_gates", "variables", "inputs", "sha_rows", "rows_used")
+    _STATS = ("rows", "poseidon_rows", "arith_gates", "variables", "inputs", "sha_rows", "rows_used", "ext_rows")
 
     def _finish(self):
         """what is derived from the recorded arrays: the cell -> variable map of the whole wire matrix (0xFFFFFFFF = zero; an unused gate slot
@@ -369,7 +392,8 @@ class WitnessProgram:
     def save(self, path):
         """the recorded circuit as one .npz of plain arrays (nothing executable): a later process loads it instead of running the builder again —
         the 'build once, prove many times' split of the reference's circuit artifacts"""
-        meta = np.array([self.W, self.R, self.log_n, self.n_values, self.n_inputs, -1 if self.input_tags is None else 0], dtype=np.int64)
+        meta = np.array([self.W, self.R, self.log_n, self.n_values, self.n_inputs, -1 if self.input_tags is None else 0, int(self.has_sha),
+                         int(self.has_ext)], dtype=np.int64)
         arrays = {k: getattr(self, k) for k in self._SAVED}
         arrays["input_tags"] = self.input_tags if self.input_tags is not None else np.zeros((0, 2), dtype=np.int64)
         arrays["seg_bounds"] = self.seg_bounds if self.seg_bounds is not None else np.zeros(0, dtype=np.uint64)
@@ -380,14 +404,15 @@ class WitnessProgram:
     def load(cls, path):
         self = object.__new__(cls)
         with np.load(path, allow_pickle=False) as z:
-            self.W, self.R, self.log_n, self.n_values, self.n_inputs, tagged = (int(v) for v in z["meta"])
+            self.W, self.R, self.log_n, self.n_values, self.n_inputs, tagged, sha, ext = (int(v) for v in z["meta"])
+            self.has_sha, self.has_ext = bool(sha), bool(ext)
             for k in cls._SAVED:
                 setattr(self, k, z[k])
             self.input_tags = None if tagged < 0 else z["input_tags"]
             self.seg_bounds = z["seg_bounds"] if z["seg_bounds"].size else None
             self.stats = dict(zip(cls._STATS, (int(v) for v in z["stats"])))
         n = 1 << self.log_n
-        if (self.consts.shape not in ((PLONK_NCONST, n), (PLONK_NCONST_SHA, n)) or self.sha_row_ids.size != self.sha_kinds.size or self.roots.size != self.n_values or not (self.cj.size == self.ci.size == self.cv.size)
+        if (self.consts.shape != (PLONK_NCONST + (4 if self.has_sha else 0) + (1 if self.has_ext else 0), n) or self.sha_row_ids.size != self.sha_kinds.size or self.roots.size != self.n_values or not (self.cj.size == self.ci.size == self.cv.size)
                 or (self.cv.size and (self.cv.max() >= self.n_values or self.cj.max() >= self.R or self.ci.max() >= n))):
             raise ValueError("not a recorded circuit of this format")
         self._finish()
@@ -418,7 +443,7 @@ class WitnessProgram:
         self._sigma = sigma                            # kept for export_raw (a compiled host commits the same circuit from it)
         # the flags follow the rows the circuit has: a selector column that is zero everywhere would still cost its constraints at every LDE point
         return PlonkCircuit(prover, self.consts, sigma, cap_height=cap_height, n_wires=self.W, n_public=len(self.public_vars),
-                            poseidon=bool(self.pos_row_ids.size), sha=self.consts.shape[0] == PLONK_NCONST_SHA)
+                            poseidon=bool(self.pos_row_ids.size), sha=self.has_sha, ext=self.has_ext)
 
     def export_raw(self, directory, sample_inputs=None, cap_height=1):
         """the recording as raw little-endian arrays + a text manifest, for a host WITHOUT Python (tests/cpp/host_replay.cpp replays it through the
@@ -445,7 +470,7 @@ class WitnessProgram:
         with open(os.path.join(directory, "manifest.txt"), "w") as f:
             f.write(f"log_n {self.log_n}\nn_wires {self.W}\nn_routed {self.R}\nn_public {len(self.public_vars)}\nn_const {self.consts.shape[0]}\n"
                     f"n_values {self.n_values}\nn_inputs {self.n_inputs}\ncap_height {cap_height}\n"
-                    f"flags {(1 if self.pos_row_ids.size else 0) | (2 if self.consts.shape[0] == PLONK_NCONST_SHA else 0)}\n")
+                    f"flags {(1 if self.pos_row_ids.size else 0) | (2 if self.has_sha else 0) | (4 if self.has_ext else 0)}\n")
             for name, (arr, dt) in arrays.items():
                 a = np.ascontiguousarray(arr).astype(dt)
                 a.tofile(os.path.join(directory, name + ".bin"))

@@ -111,10 +111,18 @@ class _G:
         return (self.sub(x[0], y[0]), self.sub(x[1], y[1]))
 
     def e_mul(self, x, y):
+        if self.b.ext_gate:                                    # one chunk of an extension row instead of four arithmetic gates
+            return self.b.ext_mul_add(x, y, (self.zero, self.zero))
         t = self.mul(x[1], y[1])
         c0 = self.b.arith(1, W_EXT, 0, x[0], y[0], t)
         u = self.mul(x[1], y[0])
         return (c0, self.b.arith(1, 1, 0, x[0], y[1], u))
+
+    def e_muladd(self, x, y, z):
+        """x * y + z"""
+        if self.b.ext_gate:
+            return self.b.ext_mul_add(x, y, z)
+        return self.e_add(z, self.e_mul(x, y))
 
     def e_scale(self, x, s):
         return (self.mul(x[0], s), self.mul(x[1], s))
@@ -286,11 +294,12 @@ def _sha_row_constraints(g, wires, q4, c2):
 
 
 def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed=None, n_public=0, cap_height=4, poseidon_consts=None,
-                      proof_id=0, sha=False):
+                      proof_id=0, sha=False, ext=False):
     """lay the whole verification of `proof` down on builder `b` (see the module docstring).  The expected statement shape and the leaf
     circuit's key are CONSTANTS of the resulting circuit.  poseidon_consts = (rc, circ, diag): the child is a Poseidon-row circuit (flags = 1,
     e.g. a proof made by this very function's circuit: recursion on recursion); its 123 row constraints are then part of the identity.
     sha: the child has SHA-256 rows (flag 2, ten constant columns): the 140 constraints of that block join the identity too.
+    ext: the child has extension-arithmetic rows (flag 4, one more constant column, last): its chunks' multiply-add equations share the gate slots.
     Returns {"public": [vars], "digest": [4 vars]}."""
     import numpy as np
     g = _G(b)
@@ -325,8 +334,8 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     # ---- statement: header (constants), public inputs, the circuit's key (constants), then the prover's caps ----------------------
     log_n = words[1] if len(words) > 1 else 0
     rb = 3
-    flags = (1 if poseidon_consts is not None else 0) | (2 if sha else 0)
-    nconst = 10 if sha else NCONST
+    flags = (1 if poseidon_consts is not None else 0) | (2 if sha else 0) | (4 if ext else 0)
+    nconst = NCONST + (4 if sha else 0) + (1 if ext else 0)
     if poseidon_consts is not None:
         poseidon_consts = tuple([int(v) for v in a] for a in poseidon_consts)
     if not 3 <= log_n <= 24:
@@ -397,7 +406,7 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     kk = 0
     for p, bi in order:
         for _ in range(n_polys[bi]):
-            Ys[p] = g.e_add(Ys[p], g.e_mul(apow[kk], openings[kk]))
+            Ys[p] = g.e_muladd(apow[kk], openings[kk], Ys[p])
             kk += 1
     L = (log_n - fb) // a_bits if log_n > fb else 0
     final_bits = log_n - a_bits * L
@@ -490,7 +499,7 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
         cur = g.e_from_base(g.zero)
         for p in range(2):
             den = g.e_sub(g.e_from_base(x), z_pts[p])
-            cur = g.e_add(cur, g.e_mul(g.e_sub(accs[p], Ys[p]), g.e_inv(den)))
+            cur = g.e_muladd(g.e_sub(accs[p], Ys[p]), g.e_inv(den), cur)
         sh = 7
         for l in range(L):
             ll = layer_log[l]
@@ -523,7 +532,7 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
                     f0, f1 = vals[2 * i], vals[2 * i + 1]
                     sm = g.e_scale_const(g.e_add(f0, f1), inv2)
                     d = g.e_scale(g.e_sub(f0, f1), m)
-                    nxt.append(g.e_add(sm, g.e_mul(bt, d)))
+                    nxt.append(g.e_muladd(bt, d, sm))
                 vals = nxt
                 cl -= 1
                 bt = g.e_mul(bt, bt)
@@ -587,7 +596,13 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
 
             def gate(xx, yy, zz, ww):
                 return g.e_mul(q_ar, g.e_sub(g.e_add(g.e_add(g.e_mul(c0, g.e_mul(xx, yy)), g.e_mul(c1, zz)), c2), ww))
-            for con in (perm, gate(*w8[0:4]), gate(*w8[4:8])):
+            g0, g1 = gate(*w8[0:4]), gate(*w8[4:8])
+            if ext:                                            # the chunk as w = x * y + z in the child's extension rows, same two slots
+                x0, x1, y0, y1, z0, z1, w0, w1 = w8
+                e0 = g.e_sub(g.e_add(g.e_muladd(x0, y0, g.e_scale_const(g.e_mul(x1, y1), W_EXT)), z0), w0)
+                e1 = g.e_sub(g.e_add(g.e_muladd(x0, y1, g.e_mul(x1, y0)), z1), w1)
+                g0, g1 = g.e_muladd(consts[-1], e0, g0), g.e_muladd(consts[-1], e1, g1)
+            for con in (perm, g0, g1):
                 ap = g.mul(ap, alpha[t])
                 acc = g.e_add(acc, g.e_scale(con, ap))
             prev = nxt
@@ -596,13 +611,13 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
             for con in pos_cons:
                 ap = g.mul(ap, alpha[t])
                 pacc = g.e_add(pacc, g.e_scale(con, ap))
-            acc = g.e_add(acc, g.e_mul(q_pos, pacc))
+            acc = g.e_muladd(q_pos, pacc, acc)
         for con in sha_cons:
             ap = g.mul(ap, alpha[t])
             acc = g.e_add(acc, g.e_scale(con, ap))
         tz, zp = g.e_from_base(g.zero), one_e
         for c in range(1 << rb):
-            tz = g.e_add(tz, g.e_mul(zp, quot[t * (1 << rb) + c]))
+            tz = g.e_muladd(zp, quot[t * (1 << rb) + c], tz)
             zp = g.e_mul(zp, zn)
         g.e_eq(acc, g.e_mul(zh, tz))
     return {"public": pub, "digest": digest}
@@ -642,20 +657,22 @@ class RecursionProgram:
     (ValueError): some copy constraint of the verifier circuit fails on its witness."""
 
     def __init__(self, prover, sample_proofs, leaf_key, num_queries, pow_bits, n_wires, poseidon_values, n_routed=None, n_public=0, cap_height=4,
-                 child_is_recursion=False, child_sha=False, combine=None, builder_wires=136):
+                 child_is_recursion=False, child_sha=False, combine=None, builder_wires=136, ext_gate=False, child_ext=False):
         """combine(b, outs) -> [public input variables]: what the node states about its children, laid down after their verification
         (outs[k] = {"public": child k's public-input variables, "digest": its 4 digest variables}).  Default: every child's public inputs and
-        digest, then the Poseidon root of the digests.  builder_wires: wire count of THIS circuit (144 when combine uses SHA rows)."""
+        digest, then the Poseidon root of the digests.  builder_wires: wire count of THIS circuit (144 when combine uses SHA rows).
+        ext_gate: lay THIS circuit down with extension-arithmetic rows (its proofs then carry flag 4: whoever verifies them in-circuit passes
+        child_ext=True)."""
         from .recursion import CircuitBuilder
         n = len(sample_proofs)
         assert n >= 1 and n & (n - 1) == 0, "a power-of-two number of proofs"
         self.prover, self.consts = prover, poseidon_values
-        b = CircuitBuilder(prover, n_wires=builder_wires)
+        b = CircuitBuilder(prover, n_wires=builder_wires, ext_gate=ext_gate)
         outs = []
         for k, proof in enumerate(sample_proofs):
             b.begin_segment()            # one proof's verifier depends on constants and on itself: the witness evaluator runs them in parallel
             outs.append(verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height,
-                                          poseidon_values if child_is_recursion else None, proof_id=k, sha=child_sha))
+                                          poseidon_values if child_is_recursion else None, proof_id=k, sha=child_sha, ext=child_ext))
             b.end_segment()
         if combine is None:
             level = []

@@ -26,7 +26,7 @@ ck = pkg.PlonkCircuit(pr, consts, sigmas)
 dw = pr.to_device(wires)
 proofs = [ck.prove_(dw, 28, 16) for _ in range(fan)]
 t0 = time.perf_counter()
-rp = vcm.RecursionProgram(pr, proofs, ck.cap(), 28, 16, 80, (rc, circ, diag))
+rp = vcm.RecursionProgram(pr, proofs, ck.cap(), 28, 16, 80, (rc, circ, diag), ext_gate=bool(int(os.environ.get("GLP_REC_EXT", "0"))))
 t_rec = time.perf_counter() - t0
 out = {"fan": fan, "record_seconds": round(t_rec, 3), "stats": rp.stats, "prog_words": int(rp.program.prog.size)}
 for rep in range(2):

@@ -369,3 +369,39 @@ def test_unswapped_poseidon_rows_pin_their_swap_cell_to_zero(setup, pkg):
     assert bad is None or not ck.verify(bad, 8, 4, public=public)
     dw.free()
     ck.free()
+
+
+def test_recursion_on_extension_rows(setup, pkg):
+    """the verifier circuit laid down with extension-arithmetic rows (GLP_CIRCUIT_EXT_GATE): a node over two leaf proofs proves and verifies
+    (native + Python verifier), and a second level verifies two such node proofs in-circuit — the child's extension-row equations evaluated at
+    zeta inside the parent (child_ext=True)"""
+    prover, oracle, rec, mr = setup
+    consts = poseidon_consts("small")
+    vc = importlib.import_module(graft.PKG_NAME + ".verifier_circuit")
+    c, s, wv = bench.synthetic_circuit(prover, 9, 16)
+    ck = pkg.PlonkCircuit(prover, c, s)
+    dw = prover.to_device(wv)
+    nq, pw = 5, 3
+    leaves = [ck.prove_(dw, nq, pw) for _ in range(2)]
+    plain = vc.RecursionProgram(prover, leaves, ck.cap(), nq, pw, 16, consts)
+    rp = vc.RecursionProgram(prover, leaves, ck.cap(), nq, pw, 16, consts, ext_gate=True)
+    assert rp.stats["ext_rows"] > 0 and rp.stats["arith_gates"] < plain.stats["arith_gates"]
+    node, public = rp.prove(leaves, 6, 4)
+    assert rp.circuit.flags & 4 and np.frombuffer(node, dtype="<u8")[7] == rp.circuit.flags
+    assert prover.plonk_verify(node, rp.key(), 6, 4, public=public), prover.last_reject
+    pref.verify_plonk(node, oracle, pos_consts=consts, public=public)
+    _, plain_public = plain.prove(leaves, 6, 4)
+    assert public == plain_public                                            # the same statement from either layout
+    top = vc.RecursionProgram(prover, [node, node], rp.key(), 6, 4, 136, consts, n_routed=80, n_public=len(public), cap_height=1,
+                              child_is_recursion=True, child_ext=True, ext_gate=True)
+    root, root_public = top.prove([node, node], 6, 4)
+    assert prover.plonk_verify(root, top.key(), 6, 4, public=root_public), prover.last_reject
+    pref.verify_plonk(root, oracle, pos_consts=consts, public=root_public)
+    bad = np.frombuffer(node, dtype="<u8").copy()
+    bad[len(bad) // 2] ^= np.uint64(1)
+    with pytest.raises(ValueError):
+        top.prove([node, bad.tobytes()], 6, 4)
+    for p in (plain, rp, top):
+        p.free()
+    dw.free()
+    ck.free()

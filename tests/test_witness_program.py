@@ -69,6 +69,38 @@ def test_c_evaluator_reproduces_the_builders_witness(oracle, which):
     assert prog.stats["inputs"] == len(inputs) and prog.stats["variables"] == len(vals)
 
 
+@pytest.mark.parametrize("which", ["plonk", "sha"])
+def test_verifier_circuit_on_extension_rows(oracle, which):
+    """the same verifier laid down with extension-arithmetic rows (ext_gate=True): fewer arithmetic gates (about a tenth: the verifier's
+    arithmetic is mostly additions and scalings, which an arithmetic gate already does in 8 wires per extension element), the C evaluator
+    (op EXTMULADD) reproduces the builder variable for variable, tampered proofs are refused"""
+    rec, vc, _, _ = _mods()
+    consts = poseidon_consts("small")
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    with open(os.path.join(G, "proofs.json")) as f:
+        g = json.load(f)[which]
+    proof = bytes.fromhex(g["proof"])
+    kw = dict(n_routed=g.get("R"), n_public=g.get("n_public", 0), poseidon_consts=consts if which != "plonk" else None, sha=which == "sha")
+    plain = rec.CircuitBuilder(_oracle_prover(oracle))
+    vc.verify_in_circuit(plain, proof, g["circuit_cap"], g["queries"], g["pow_bits"], g["W"], **kw)
+    b = rec.CircuitBuilder(_oracle_prover(oracle), ext_gate=True)
+    vc.verify_in_circuit(b, proof, g["circuit_cap"], g["queries"], g["pow_bits"], g["W"], **kw)
+    prog = b.program()
+    n_plain = sum(len(r) for rows in plain.arith_rows.values() for r in rows)
+    assert prog.stats["ext_rows"] > 0 and prog.has_ext and prog.consts.shape[0] == 7
+    assert prog.stats["arith_gates"] < 0.95 * n_plain
+    inputs, ws = prog.inputs_from_words([proof])
+    vals = prog.evaluate(consts, inputs)
+    assert np.array_equal(vals, np.array(b.values, dtype=np.uint64))
+    w = np.frombuffer(proof, dtype="<u8").copy()
+    for t in range(9, len(w), max(1, len(w) // 25)):
+        bad = w.copy()
+        bad[t] ^= np.uint64(1)
+        with pytest.raises(ValueError):
+            i2, ws2 = prog.inputs_from_words([bad.tobytes()])
+            prog.check_words(prog.evaluate(consts, i2), ws2)
+
+
 def test_segments_evaluate_in_parallel_and_false_independence_is_refused(oracle, tmp_path):
     """two proofs' verifier sub-circuits recorded as independent segments: glp_witness_eval_mt on 4 threads reproduces the builder's values
     (the constants both segments read were hoisted into the prefix); a segment that reads the other segment's variable is refused"""
