@@ -132,12 +132,11 @@ def _prove_local(prove_leaf, ids):
 
 
 def reduce_verify(verify_leaf, proofs, device=None, comm=None):
-    """The Reduce step as far as this build goes: every gathered leaf proof is checked by the native
-    verifier (``verify_leaf(proof_bytes) -> bool``, e.g. ``PlonkCircuit.verify``, or a list of them — one per
+    """The Reduce step in its NATIVE form (the recursive forms are reduce_recursive / reduce_tree / reduce_tree_distributed): every gathered leaf
+    proof is checked by the native verifier (``verify_leaf(proof_bytes) -> bool``, e.g. ``PlonkCircuit.verify``, or a list of them — one per
     ctx — run by one host thread each), the work split across
     ranks — rank r checks the leaves PROVED BY rank r+1 — and the verdicts are combined with one
-    all-reduce(MIN).  Upstream folds the leaves with a tree of recursive verifier circuits into one
-    proof; here the result is a boolean ("all leaves verify"), not a succinct proof."""
+    all-reduce(MIN).  The result is a boolean ("all leaves verify"), not a succinct proof: that is what the recursive forms produce."""
     rank, world = _world(comm)
     owner = (rank + 1) % world
     ids = list(range(owner, len(proofs), world))

@@ -8,10 +8,10 @@ gates out in rows (a row's constants are shared by its 20 gate slots, so rows ar
 the witness matrix, and returns a ``PlonkCircuit`` ready to prove on the GPU.  Poseidon rows carry only their 12 inputs and 12
 outputs as variables; their 106 S-box-input wires are filled on the device (``glp_poseidon_gate_fill_rows``).
 
-What is in-circuit here, and what is not: the AGGREGATION of the leaf proofs — a Poseidon Merkle tree over the
-leaf-proof digests, every two-to-one hash a constrained Poseidon row — and Merkle-path verification to a cap (conditional swaps
-by arithmetic gates).  The leaf proofs themselves are still verified natively (host arithmetic): an in-circuit FRI verifier
-needs extension-field arithmetic gadgets and the transcript in-circuit, listed in DESIGN.md.
+What lives here: the builder and its row kinds (arithmetic gates, Poseidon rows with their swap input, SHA-256 rows, extension
+rows), the recorded circuit (``WitnessProgram``: layout + straight-line witness program, save / load / raw export), the aggregation of leaf-proof
+digests into a Poseidon Merkle root, in-circuit Merkle paths.  The in-circuit VERIFIER of leaf proofs is verifier_circuit.py; the SHA-256 gadgets and
+the statements on them are gadgets.py.
 """
 import numpy as np
 
