@@ -132,6 +132,10 @@ def parse_and_verify(proof_bytes, oracle, challenger=None, words=None, pos=0, al
         raise VerifyError("bad tag")
     if not (1 <= n_pts <= 4) or nb == 0 or nb > 64:
         raise VerifyError("bad header")
+    # the remaining header fields are untrusted sizes and shift counts: bound them before they are used as such
+    if not (1 <= log_n <= 32) or rb > 8 or not (1 <= a <= 8) or fb > 32 or not (1 <= nq <= 1 << 12) or pow_bits > 63 or not (0 < shift < P) \
+            or log_n + rb > 40:
+        raise VerifyError("bad header")
     # rate 1 proves nothing (every word is a codeword): min_rate_bits=0 exists only so a test can show that a forged
     # rate-1 proof is otherwise well formed
     if rb < max(min_rate_bits, 0) or (rb == 0 and min_rate_bits > 0):
