@@ -99,7 +99,9 @@ def verify_signers(prover, poseidon_consts, signer_digest, pubkeys, signed, sign
     carry a digest of (target validator keys, signed flags); the consumer, who holds the keys, the flags and the signatures, checks that
       1. the digest of (pubkeys, signed) IS the proof's signer digest — the proof's power rules were about exactly these flags, and
       2. every FLAGGED validator's signature verifies ([SPEC] RFC 8032, on the GPU witness kernel) over its sign bytes.
-    Unflagged validators need no signature.  Returns True / False."""
+    Unflagged validators need no signature.  sign_bytes[i] is validator i's canonical vote: the consumer BUILDS it around the target header hash the
+    proof exposes (block id, height, round, its own timestamp, chain id — [RECALLED] CanonicalVote), otherwise the signatures are about something
+    else; this function does not know the vote format and takes the bytes as given.  Returns True / False."""
     import importlib
     gd = importlib.import_module(__package__ + ".gadgets")
     if [int(v) for v in signer_digest] != gd.signer_digest_host(poseidon_consts, pubkeys, signed):
