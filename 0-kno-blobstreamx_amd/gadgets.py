@@ -15,6 +15,7 @@ Statements (all build-defined, NOT upstream's circuits; encodings are public spe
   ``data_commitment_rows_circuit`` / ``data_commitment_circuit``   the RFC 6962 root over abi.encode(height, dataRoot) tuples (public) = the data commitment
   ``validator_set_statement``     validators_hash from keys + powers (variable-length protobuf leaves) and the > 2/3 voting-power rule
   ``header_hash_statement``       a header hash over its 14 encoded fields, one field bound to bytes computed in-circuit
+  ``data_commitment_chain_statement``   the header-chain form: headers linked through last_block_id, their data_hash fields feeding the commitment
   ``step_statement`` / ``skip_statement``   the light-client step (chain link through last_block_id, one set, > 2/3) and skip (two sets, > 2/3 of
                                   the target power, > 1/3 of the trusted power) statements, with a SIGNER DIGEST as public input
 Ed25519 is NOT constrained anywhere: the flags saying who signed are witnesses, exposed through the signer digest so that
@@ -500,6 +501,50 @@ def commit_check_circuit(prover, header_fields, validators_field, pubkeys, votin
     vh = b"".join(struct.pack(">I", b.value(w)) for w in vroot)
     ck, dw, public = b.build()
     return ck, dw, public, hh, vh
+
+
+def data_commitment_chain_statement(b, g, start_header_fields, headers, first_height):
+    """The header-chain form of the data commitment ([RECALLED] blobstreamx DataCommitmentCircuit: prove_data_commitment walks the headers between
+    two trusted hashes): a start header and n following headers, each given as its 14 field encodings, with
+      * header k's last_block_id (field 4: 0x0a 0x20 || hash || 38 opaque bytes) carrying the hash of header k-1 AS COMPUTED IN THIS CIRCUIT — the
+        chain from the start header to the last one is constrained link by link;
+      * header k's data_hash (field 6: BytesValue, 0x0a 0x20 || 32 bytes) feeding leaf k of the data commitment: the RFC 6962 root over
+        abi.encode(first_height + k, data_hash_k) for the n headers AFTER the start header (n a power of two; heights are constants of the circuit —
+        binding them to the headers' own height fields is not done).
+    Returns (start header hash, last header hash, data commitment root): 8 word variables each."""
+    n = len(headers)
+    assert n >= 1 and n & (n - 1) == 0
+    wrap = lambda ws: [b.constant(0x0a), b.constant(0x20)] + [x for w in ws for x in g.bytes_of_word(w)]
+    prev = header_hash_statement(b, g, start_header_fields)
+    h_start = prev
+    leaves = []
+    for k, fields in enumerate(headers):
+        if len(bytes(fields[4])) < 34 or len(bytes(fields[6])) != 34:
+            raise ValueError("header fields 4 (last_block_id) / 6 (data_hash) do not have the expected encodings")
+        data_hash = [g.byte(b.var(v)) for v in bytes(fields[6])[2:]]
+        block_id = wrap(prev) + [g.byte(b.var(v)) for v in bytes(fields[4])[34:]]
+        prev = header_hash_statement(b, g, fields, bound={4: block_id, 6: [b.constant(0x0a), b.constant(0x20)] + data_hash})
+        height_words = [b.constant(v) for v in struct.unpack(">8I", int(first_height + k).to_bytes(32, "big"))]
+        root_words = [g.word_from_bytes(data_hash[j:j + 4]) for j in range(0, 32, 4)]
+        leaves.append(g.hash_prefixed_64(0x00, height_words + root_words))
+    while len(leaves) > 1:
+        leaves = [g.hash_prefixed_64(0x01, leaves[j] + leaves[j + 1]) for j in range(0, len(leaves), 2)]
+    return h_start, prev, leaves[0]
+
+
+def data_commitment_chain_circuit(prover, start_header_fields, headers, first_height):
+    """the circuit of data_commitment_chain_statement: public inputs = start header hash, end header hash, data commitment (8 words each).
+    Returns (circuit, device wires, public values, start hash bytes, end hash bytes, commitment bytes)."""
+    from . import SHA_GATE_WIRES
+    b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
+    g = Sha256Rows(b)
+    hs, he, root = data_commitment_chain_statement(b, g, start_header_fields, headers, first_height)
+    for w in hs + he + root:
+        b.public_input(w)
+    to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
+    out = (to_bytes(hs), to_bytes(he), to_bytes(root))
+    ck, dw, public = b.build()
+    return (ck, dw, public) + out
 
 
 def validator_set_circuit(prover, pubkeys, voting_powers, signed, numerator=2, denominator=3):

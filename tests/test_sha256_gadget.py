@@ -354,6 +354,72 @@ def test_step_statement_links_the_headers():
     assert new_v == _tm_tree(want_v2)
 
 
+def _chain_reference(start, headers, first_height):
+    """hashlib restatement: link every header to its predecessor's hash, then the data commitment over (height, data_hash)"""
+    prev = _tm_tree(start)
+    h_start = prev
+    leaves = []
+    for k, f in enumerate(headers):
+        f = list(f)
+        f[4] = b"\x0a\x20" + prev + f[4][34:]
+        prev = _tm_tree(f)
+        leaves.append(hashlib.sha256(b"\x00" + int(first_height + k).to_bytes(32, "big") + f[6][2:]).digest())
+    while len(leaves) > 1:
+        leaves = [hashlib.sha256(b"\x01" + leaves[j] + leaves[j + 1]).digest() for j in range(0, len(leaves), 2)]
+    return h_start, prev, leaves[0]
+
+
+def _chain_case(rng, n):
+    def hdr():
+        f = _header_fields(rng)
+        f[6] = b"\x0a\x20" + f[6][2:]                                # data_hash: a BytesValue
+        return f
+    return hdr(), [hdr() for _ in range(n)]
+
+
+def test_data_commitment_chain_statement():
+    """the header-chain form: two headers after a start header, each linked through last_block_id to the in-circuit hash of its predecessor, their
+    data_hash fields feeding the commitment; equals the hashlib restatement, and the commitment is the one blobstream.data_commitment's formula gives"""
+    gd, rec, bs = _mods()
+    rng = np.random.default_rng(95)
+    start, headers = _chain_case(rng, 2)
+    b = rec.CircuitBuilder(object(), n_wires=144)
+    g = gd.Sha256Rows(b)
+    hs, he, root = gd.data_commitment_chain_statement(b, g, start, headers, 1000)
+    to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
+    want = _chain_reference(start, headers, 1000)
+    assert (to_bytes(hs), to_bytes(he), to_bytes(root)) == want
+    assert want[2] == _tm_root([1000, 1001], [h[6][2:] for h in headers])
+    with pytest.raises(ValueError):
+        bad = [list(h) for h in headers]
+        bad[1][6] = bad[1][6][:-1]
+        bb = rec.CircuitBuilder(object(), n_wires=144)
+        gd.data_commitment_chain_statement(bb, gd.Sha256Rows(bb), start, bad, 1000)
+
+
+@pytest.mark.gpu
+def test_data_commitment_chain_circuit_proves(prover, oracle, pkg):
+    gd, rec, bs = _mods()
+    rc, circ, diag = poseidon_consts("small")
+    prover.set_poseidon_constants(rc, circ, diag)
+    oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
+    rng = np.random.default_rng(96)
+    start, headers = _chain_case(rng, 4)
+    ck, dw, public, hb_s, hb_e, root = gd.data_commitment_chain_circuit(prover, start, headers, 2_000_000)
+    want = _chain_reference(start, headers, 2_000_000)
+    assert (hb_s, hb_e, root) == want
+    assert root == bs.data_commitment(prover, [2_000_000 + k for k in range(4)], [h[6][2:] for h in headers])      # = the GPU witness kernel's
+    assert public == [w for part in want for w in struct.unpack(">8I", part)]
+    proof = ck.prove_(dw, 10, 6, public=public)
+    assert ck.verify(proof, 10, 6, public=public), prover.last_reject
+    pref.verify_plonk(proof, oracle, pos_consts=(rc, circ, diag), public=public)
+    other = list(public)
+    other[20] ^= 1                                                      # another commitment
+    assert not ck.verify(proof, 10, 6, public=other)
+    dw.free()
+    ck.free()
+
+
 @pytest.mark.gpu
 def test_step_circuit_proves(prover, oracle, pkg):
     gd, rec, bs = _mods()
