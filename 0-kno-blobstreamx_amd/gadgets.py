@@ -509,13 +509,16 @@ def data_commitment_chain_statement(b, g, start_header_fields, headers, first_he
       * header k's last_block_id (field 4: 0x0a 0x20 || hash || 38 opaque bytes) carrying the hash of header k-1 AS COMPUTED IN THIS CIRCUIT — the
         chain from the start header to the last one is constrained link by link;
       * header k's data_hash (field 6: BytesValue, 0x0a 0x20 || 32 bytes) feeding leaf k of the data commitment: the RFC 6962 root over
-        abi.encode(first_height + k, data_hash_k) for the n headers AFTER the start header (n a power of two; heights are constants of the circuit —
-        binding them to the headers' own height fields is not done).
+        abi.encode(first_height + k, data_hash_k) for the n headers AFTER the start header (n a power of two);
+      * every header's height field (field 2: Int64Value, 0x08 || varint) is a CONSTANT of the circuit — first_height - 1 for the start header,
+        first_height + k after it — so the heights in the commitment's tuples are the heights the hashed headers carry.
     Returns (start header hash, last header hash, data commitment root): 8 word variables each."""
+    from .blobstream import encode_varint
     n = len(headers)
-    assert n >= 1 and n & (n - 1) == 0
+    assert n >= 1 and n & (n - 1) == 0 and first_height >= 1
     wrap = lambda ws: [b.constant(0x0a), b.constant(0x20)] + [x for w in ws for x in g.bytes_of_word(w)]
-    prev = header_hash_statement(b, g, start_header_fields)
+    height_field = lambda h: [b.constant(v) for v in b"\x08" + encode_varint(int(h))]
+    prev = header_hash_statement(b, g, start_header_fields, bound={2: height_field(first_height - 1)})
     h_start = prev
     leaves = []
     for k, fields in enumerate(headers):
@@ -523,7 +526,8 @@ def data_commitment_chain_statement(b, g, start_header_fields, headers, first_he
             raise ValueError("header fields 4 (last_block_id) / 6 (data_hash) do not have the expected encodings")
         data_hash = [g.byte(b.var(v)) for v in bytes(fields[6])[2:]]
         block_id = wrap(prev) + [g.byte(b.var(v)) for v in bytes(fields[4])[34:]]
-        prev = header_hash_statement(b, g, fields, bound={4: block_id, 6: [b.constant(0x0a), b.constant(0x20)] + data_hash})
+        prev = header_hash_statement(b, g, fields, bound={2: height_field(first_height + k), 4: block_id,
+                                                          6: [b.constant(0x0a), b.constant(0x20)] + data_hash})
         height_words = [b.constant(v) for v in struct.unpack(">8I", int(first_height + k).to_bytes(32, "big"))]
         root_words = [g.word_from_bytes(data_hash[j:j + 4]) for j in range(0, 32, 4)]
         leaves.append(g.hash_prefixed_64(0x00, height_words + root_words))

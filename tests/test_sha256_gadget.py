@@ -356,11 +356,16 @@ def test_step_statement_links_the_headers():
 
 def _chain_reference(start, headers, first_height):
     """hashlib restatement: link every header to its predecessor's hash, then the data commitment over (height, data_hash)"""
+    _, _, bs = _mods()
+    hf = lambda h: b"\x08" + bs.encode_varint(h)
+    start = list(start)
+    start[2] = hf(first_height - 1)
     prev = _tm_tree(start)
     h_start = prev
     leaves = []
     for k, f in enumerate(headers):
         f = list(f)
+        f[2] = hf(first_height + k)
         f[4] = b"\x0a\x20" + prev + f[4][34:]
         prev = _tm_tree(f)
         leaves.append(hashlib.sha256(b"\x00" + int(first_height + k).to_bytes(32, "big") + f[6][2:]).digest())
