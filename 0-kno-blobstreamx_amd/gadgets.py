@@ -348,7 +348,7 @@ def validator_set_statement(b, g, pubkeys, voting_powers, signed, numerator=2, d
     return vs["root"], got, vs["total"]
 
 
-def skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index):
+def skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index, heights=None, max_skip=1 << 20):
     """The non-cryptographic statement of a light-client SKIP ([RECALLED] tendermintx verify_skip; blobstream.skip_witness computes the same as a
     witness): from a trusted header to a target header that need not be its successor,
       1. the trusted header's next_validators_hash field (index 8) is BytesValue(hash of the trusted set),
@@ -358,8 +358,10 @@ def skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, t
          by copy constraints) hold more than 1/3 of the TRUSTED set's power.
     trusted / target = (pubkeys, voting_powers); header fields = 14 opaque byte strings each (the bound field's own bytes are ignored).
     NOT constrained: that the flagged validators signed the target header (Ed25519) — but the proof exposes WHO was flagged (signer digest over
-    the target set's keys and flags), so a consumer checks exactly those signatures natively (blobstream.verify_signers).  Returns (trusted header
-    hash, target header hash, signer digest)."""
+    the target set's keys and flags), so a consumer checks exactly those signatures natively (blobstream.verify_signers).
+    heights = (trusted block, target block), optional: both headers' height fields (field 2) are then tied to variables, with
+    trusted < target <= trusted + max_skip shown by range checks; returned as a fourth element [trusted_block, target_block].
+    Returns (trusted header hash, target header hash, signer digest[, blocks])."""
     T = _validator_set(b, g, *trusted)
     V = _validator_set(b, g, *target)
     flags = _flags(b, signed)
@@ -375,9 +377,43 @@ def skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, t
     _more_than(b, g, got, V["total"], 2, 3)
     _more_than(b, g, overlap, T["total"], 1, 3)
     wrap = lambda root: [b.constant(0x0a), b.constant(0x20)] + [x for w in root for x in g.bytes_of_word(w)]
-    h_trusted = header_hash_statement(b, g, trusted_header_fields, bound={8: wrap(T["root"])})
-    h_target = header_hash_statement(b, g, target_header_fields, bound={7: wrap(V["root"])})
-    return h_trusted, h_target, _signer_digest(b, g, V["keys"], flags)
+    bound_t, bound_v, blocks = {8: wrap(T["root"])}, {7: wrap(V["root"])}, None
+    if heights is not None:
+        ht_var, bound_t[2] = _height_field(b, g, heights[0])
+        hv_var, bound_v[2] = _height_field(b, g, heights[1])
+        gap = b.sub(hv_var, ht_var)                                                     # 1 <= gap <= max_skip: gap - 1 and max_skip - gap are 32-bit
+        b.range32(b.arith(0, 1, P - 1, gap, gap, gap))
+        b.range32(b.arith(0, P - 1, int(max_skip), gap, gap, gap))
+        blocks = [ht_var, hv_var]
+    h_trusted = header_hash_statement(b, g, trusted_header_fields, bound=bound_t)
+    h_target = header_hash_statement(b, g, target_header_fields, bound=bound_v)
+    out = (h_trusted, h_target, _signer_digest(b, g, V["keys"], flags))
+    return out if blocks is None else out + (blocks,)
+
+
+def _height_field(b, g, height):
+    """a header's height as a VARIABLE and its field encoding (Int64Value: 0x08 || varint) as byte variables tied to it: the varint's 7-bit groups
+    are range-checked witnesses (their number is a constant of the circuit), height = sum g_j * 128^j.  Heights below 2^49."""
+    height = int(height)
+    if not 0 < height < (1 << 49):
+        raise ValueError("height out of range")
+    groups = []
+    p = height
+    while True:
+        groups.append(p & 0x7F)
+        p >>= 7
+        if not p:
+            break
+    gv = []
+    for gval in groups:
+        v = b.var(gval)
+        b.range32(v)
+        b.range32(b.arith(1, 0, 0, v, b.constant(1 << 25), v))
+        gv.append(v)
+    hv = gv[-1]
+    for v in reversed(gv[:-1]):
+        hv = b.arith(1, 1, 0, hv, b.constant(128), v)
+    return hv, [b.constant(0x08)] + [b.arith(0, 1, 0x80, v, v, v) for v in gv[:-1]] + [gv[-1]]
 
 
 def _signer_digest(b, g, keys, flags):
@@ -405,7 +441,7 @@ def signer_digest_host(poseidon_consts, pubkeys, signed):
     return [int(v) for v in state[:4]]
 
 
-def step_statement(b, g, trusted_header_fields, target_header_fields, validators, signed):
+def step_statement(b, g, trusted_header_fields, target_header_fields, validators, signed, trusted_height=None):
     """The non-cryptographic statement of a light-client STEP ([RECALLED] tendermintx verify_step): the target header is the trusted header's
     successor —
       1. the trusted header's next_validators_hash (field 8) and the target header's validators_hash (field 7) are BytesValue(hash of ONE set),
@@ -414,7 +450,9 @@ def step_statement(b, g, trusted_header_fields, target_header_fields, validators
       3. the flagged validators hold more than 2/3 of the set's power.
     validators = (pubkeys, voting_powers).  The last 38 bytes of the target's field 4 (0x12 0x24 || part-set header) stay opaque witnesses.
     NOT constrained: the Ed25519 signatures — but the proof exposes WHO was flagged (signer digest, 4 words), so a consumer checks exactly those
-    signatures natively.  Returns (trusted header hash, target header hash, signer digest)."""
+    signatures natively.  trusted_height (optional): both headers' height fields (field 2) are then tied to variables — the trusted block number and
+    its successor, trusted + 1 — returned as a fourth element [trusted_block, target_block] (upstream's public inputs name them).
+    Returns (trusted header hash, target header hash, signer digest[, blocks])."""
     V = _validator_set(b, g, *validators)
     flags = _flags(b, signed)
     got = b.constant(0)
@@ -422,22 +460,31 @@ def step_statement(b, g, trusted_header_fields, target_header_fields, validators
         got = b.arith(1, 1, 0, f, pw, got)
     _more_than(b, g, got, V["total"], 2, 3)
     wrap = lambda ws: [b.constant(0x0a), b.constant(0x20)] + [x for w in ws for x in g.bytes_of_word(w)]
-    h_trusted = header_hash_statement(b, g, trusted_header_fields, bound={8: wrap(V["root"])})
+    bound_t, bound_v, blocks = {8: wrap(V["root"])}, {}, None
+    if trusted_height is not None:
+        ht_var, bound_t[2] = _height_field(b, g, trusted_height)
+        hv_var, bound_v[2] = _height_field(b, g, int(trusted_height) + 1)
+        b.assert_equal(b.arith(0, 1, 1, ht_var, ht_var, ht_var), hv_var)              # the successor: target = trusted + 1
+        blocks = [ht_var, hv_var]
+    h_trusted = header_hash_statement(b, g, trusted_header_fields, bound=bound_t)
     tail = bytes(target_header_fields[4])[34:]
     if len(bytes(target_header_fields[4])) < 34:
         raise ValueError("the target header's last_block_id field is shorter than 0x0a 0x20 || hash")
     block_id = wrap(h_trusted) + [g.byte(b.var(v)) for v in tail]
-    h_target = header_hash_statement(b, g, target_header_fields, bound={7: wrap(V["root"]), 4: block_id})
-    return h_trusted, h_target, _signer_digest(b, g, V["keys"], flags)
+    bound_v.update({7: wrap(V["root"]), 4: block_id})
+    h_target = header_hash_statement(b, g, target_header_fields, bound=bound_v)
+    out = (h_trusted, h_target, _signer_digest(b, g, V["keys"], flags))
+    return out if blocks is None else out + (blocks,)
 
 
-def step_circuit(prover, trusted_header_fields, target_header_fields, validators, signed):
-    """the circuit of step_statement: public inputs = the trusted header hash, the target header hash (8 words each), the signer digest (4)"""
+def step_circuit(prover, trusted_header_fields, target_header_fields, validators, signed, trusted_height=None):
+    """the circuit of step_statement: public inputs = the trusted header hash, the target header hash (8 words each), the signer digest (4) and,
+    with trusted_height, the two block numbers (trusted, trusted + 1)"""
     from . import SHA_GATE_WIRES
     b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
     g = Sha256Rows(b)
-    ht, hv, sd = step_statement(b, g, trusted_header_fields, target_header_fields, validators, signed)
-    for w in ht + hv + sd:
+    ht, hv, sd, *blocks = step_statement(b, g, trusted_header_fields, target_header_fields, validators, signed, trusted_height)
+    for w in ht + hv + sd + (blocks[0] if blocks else []):
         b.public_input(w)
     to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
     hb_t, hb_v = to_bytes(ht), to_bytes(hv)
@@ -445,14 +492,15 @@ def step_circuit(prover, trusted_header_fields, target_header_fields, validators
     return ck, dw, public, hb_t, hb_v
 
 
-def skip_circuit(prover, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index):
-    """the circuit of skip_statement: public inputs = the trusted header hash, the target header hash (8 words each), the signer digest (4 words).
-    Returns (circuit, device wires, public values, trusted header hash bytes, target header hash bytes); ValueError when a threshold is not met."""
+def skip_circuit(prover, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index, heights=None, max_skip=1 << 20):
+    """the circuit of skip_statement: public inputs = the trusted header hash, the target header hash (8 words each), the signer digest (4 words) and,
+    with heights, the two block numbers.  Returns (circuit, device wires, public values, trusted header hash bytes, target header hash bytes);
+    ValueError when a threshold (or the block gap) is not met."""
     from . import SHA_GATE_WIRES
     b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
     g = Sha256Rows(b)
-    ht, hv, sd = skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index)
-    for w in ht + hv + sd:
+    ht, hv, sd, *blocks = skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, target, signed, trusted_index, heights, max_skip)
+    for w in ht + hv + sd + (blocks[0] if blocks else []):
         b.public_input(w)
     to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
     hb_t, hb_v = to_bytes(ht), to_bytes(hv)

@@ -425,6 +425,39 @@ def test_data_commitment_chain_circuit_proves(prover, oracle, pkg):
     ck.free()
 
 
+def test_step_and_skip_bind_the_block_numbers():
+    """with heights given, the headers' height fields are tied to block-number variables: a step needs target = trusted + 1, a skip
+    trusted < target <= trusted + max_skip; the header hashes equal the hashlib restatement with those height encodings"""
+    gd, rec, bs = _mods()
+    rng = np.random.default_rng(97)
+    keys, powers = _validators(rng, 3)
+    hf_t, hf_v = _header_fields(rng), _header_fields(rng)
+    hfield = lambda h: b"\x08" + bs.encode_varint(h)
+    b = rec.CircuitBuilder(_HostPoseidon(), n_wires=144)
+    g = gd.Sha256Rows(b)
+    ht, hv, sd, blocks = gd.step_statement(b, g, hf_t, hf_v, (keys, powers), [True] * 3, trusted_height=12345)
+    assert [b.value(v) for v in blocks] == [12345, 12346]
+    vh = _validators_hash(bs, keys, powers)
+    want_t = list(hf_t)
+    want_t[2], want_t[8] = hfield(12345), b"\x0a\x20" + vh
+    want_v = list(hf_v)
+    want_v[2], want_v[7] = hfield(12346), b"\x0a\x20" + vh
+    want_v[4] = b"\x0a\x20" + _tm_tree(want_t) + hf_v[4][34:]
+    to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
+    assert to_bytes(ht) == _tm_tree(want_t) and to_bytes(hv) == _tm_tree(want_v)
+    # skip: the gap rule
+    tk, tp, vk, vp, idx, signed, hs_t, hs_v = _skip_case(rng)
+    for heights, ok in (((1000, 1001), True), ((1000, 1000 + 500), True), ((1000, 1000), False), ((1000, 999), False), ((1000, 1000 + 501), False)):
+        bb = rec.CircuitBuilder(_HostPoseidon(), n_wires=144)
+        gg = gd.Sha256Rows(bb)
+        if ok:
+            out = gd.skip_statement(bb, gg, hs_t, (tk, tp), hs_v, (vk, vp), signed, idx, heights=heights, max_skip=500)
+            assert [bb.value(v) for v in out[3]] == list(heights)
+        else:
+            with pytest.raises(ValueError):
+                gd.skip_statement(bb, gg, hs_t, (tk, tp), hs_v, (vk, vp), signed, idx, heights=heights, max_skip=500)
+
+
 @pytest.mark.gpu
 def test_step_circuit_proves(prover, oracle, pkg):
     gd, rec, bs = _mods()
@@ -457,12 +490,14 @@ def test_skip_circuit_proves(prover, oracle, pkg):
     oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
     rng = np.random.default_rng(89)
     tk, tp, vk, vp, idx, signed, hf_t, hf_v = _skip_case(rng)
-    ck, dw, public, hb_t, hb_v = gd.skip_circuit(prover, hf_t, (tk, tp), hf_v, (vk, vp), signed, idx)
+    ck, dw, public, hb_t, hb_v = gd.skip_circuit(prover, hf_t, (tk, tp), hf_v, (vk, vp), signed, idx, heights=(4_000_000, 4_000_700), max_skip=1000)
     want_t, want_v = list(hf_t), list(hf_v)
+    want_t[2], want_v[2] = b"\x08" + bs.encode_varint(4_000_000), b"\x08" + bs.encode_varint(4_000_700)
     want_t[8] = b"\x0a\x20" + bs.validator_set_hash(prover, tk, tp)           # the GPU witness kernel's hashes
     want_v[7] = b"\x0a\x20" + bs.validator_set_hash(prover, vk, vp)
     assert hb_t == _tm_tree(want_t) and hb_v == _tm_tree(want_v)
-    assert public == list(struct.unpack(">8I", hb_t)) + list(struct.unpack(">8I", hb_v)) + gd.signer_digest_host((rc, circ, diag), vk, signed)
+    assert public == list(struct.unpack(">8I", hb_t)) + list(struct.unpack(">8I", hb_v)) + gd.signer_digest_host((rc, circ, diag), vk, signed) \
+        + [4_000_000, 4_000_700]                                        # ... and the two block numbers, tied to the headers' height fields
     proof = ck.prove_(dw, 10, 6, public=public)
     assert ck.verify(proof, 10, 6, public=public), prover.last_reject
     pref.verify_plonk(proof, oracle, pos_consts=(rc, circ, diag), public=public)
