@@ -18,6 +18,7 @@ Statements (all build-defined, NOT upstream's circuits; encodings are public spe
   ``data_commitment_chain_statement``   the header-chain form: headers linked through last_block_id, their data_hash fields feeding the commitment
   ``step_statement`` / ``skip_statement``   the light-client step (chain link through last_block_id, one set, > 2/3) and skip (two sets, > 2/3 of
                                   the target power, > 1/3 of the trusted power) statements, with a SIGNER DIGEST as public input
+  ``combined_skip_circuit``       skip + header chain + data commitment in one circuit (CombinedSkip's shape minus Ed25519)
 Ed25519 is NOT constrained anywhere: the flags saying who signed are witnesses, exposed through the signer digest so that
 ``blobstream.verify_signers`` checks exactly those signatures natively (GPU kernel).  data_commitment_mr.py builds the range MapReduce on top.
 """
@@ -595,6 +596,31 @@ def data_commitment_chain_circuit(prover, start_header_fields, headers, first_he
         b.public_input(w)
     to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
     out = (to_bytes(hs), to_bytes(he), to_bytes(root))
+    ck, dw, public = b.build()
+    return (ck, dw, public) + out
+
+
+def combined_skip_circuit(prover, trusted_header_fields, trusted, chain_headers, target, signed, trusted_index, trusted_height, max_skip=1 << 20):
+    """CombinedSkip's shape in ONE circuit ([RECALLED] blobstreamx CombinedSkipCircuit = skip + the data commitment of the skipped range), minus the
+    Ed25519 half: chain_headers = the headers AFTER the trusted one up to and including the target (a power-of-two count), each as its 14 field
+    encodings.  Constraints: the skip statement between the trusted header and the last chain header (validator sets, 2/3 and 1/3 power rules, block
+    numbers) AND the header chain with its data commitment (data_commitment_chain_statement) — the two halves meet in the trusted and target header
+    hashes, which each half computes from the fields and which are copy-constrained equal.  Public inputs: trusted header hash, target header
+    hash (8 words each), signer digest (4), trusted block, target block, data commitment (8 words).
+    Returns (circuit, device wires, public values, trusted hash bytes, target hash bytes, commitment bytes)."""
+    from . import SHA_GATE_WIRES
+    b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
+    g = Sha256Rows(b)
+    n = len(chain_headers)
+    ht, hv, sd, blocks = skip_statement(b, g, trusted_header_fields, trusted, chain_headers[-1], target, signed, trusted_index,
+                                        heights=(trusted_height, trusted_height + n), max_skip=max_skip)
+    hs, he, root = data_commitment_chain_statement(b, g, trusted_header_fields, chain_headers, trusted_height + 1)
+    for x, y in zip(ht + hv, hs + he):
+        b.assert_equal(x, y)                       # both halves are about the SAME two headers
+    for w in ht + hv + sd + blocks + root:
+        b.public_input(w)
+    to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
+    out = (to_bytes(ht), to_bytes(hv), to_bytes(root))
     ck, dw, public = b.build()
     return (ck, dw, public) + out
 

@@ -674,3 +674,41 @@ def test_hybrid_commit_check_with_real_signatures(prover, oracle, pkg):
     assert not bs.verify_signers(prover, consts, digest, keys, signed, missing, msgs)
     dw.free()
     ck.free()
+
+
+@pytest.mark.gpu
+def test_combined_skip_circuit(prover, oracle, pkg):
+    """CombinedSkip's shape in one circuit: a trusted header, four chained headers ending in the target, two validator sets; the skip rules and
+    the chain + data commitment meet in the two header hashes.  The headers given must be CONSISTENT (real field bytes where the other half binds
+    them): a chain whose target header carries another validators_hash cannot be laid down."""
+    gd, rec, bs = _mods()
+    rc, circ, diag = poseidon_consts("small")
+    prover.set_poseidon_constants(rc, circ, diag)
+    oracle.orc_poseidon_set_constants(ptr(rc), ptr(circ), ptr(diag))
+    rng = np.random.default_rng(98)
+    tk, tp, vk, vp, idx, signed, _, _ = _skip_case(rng)
+    h0 = 5_000_000
+    hfield = lambda h: b"\x08" + bs.encode_varint(h)
+    trusted, chain = _chain_case(rng, 4)
+    trusted[2], trusted[8] = hfield(h0), b"\x0a\x20" + _validators_hash(bs, tk, tp)
+    prev = _tm_tree(trusted)
+    for k, f in enumerate(chain):                                       # make the headers a real chain (what a node would hand the prover)
+        f[2] = hfield(h0 + 1 + k)
+        f[4] = b"\x0a\x20" + prev + f[4][34:]
+        if k == 3:
+            f[7] = b"\x0a\x20" + _validators_hash(bs, vk, vp)
+        prev = _tm_tree(f)
+    ck, dw, public, hb_t, hb_v, root = gd.combined_skip_circuit(prover, trusted, (tk, tp), chain, (vk, vp), signed, idx, h0, max_skip=1000)
+    assert hb_t == _tm_tree(trusted) and hb_v == prev
+    assert root == bs.data_commitment(prover, [h0 + 1 + k for k in range(4)], [f[6][2:] for f in chain])
+    assert public == list(struct.unpack(">8I", hb_t)) + list(struct.unpack(">8I", hb_v)) + gd.signer_digest_host((rc, circ, diag), vk, signed) \
+        + [h0, h0 + 4] + list(struct.unpack(">8I", root))
+    proof = ck.prove_(dw, 10, 6, public=public)
+    assert ck.verify(proof, 10, 6, public=public), prover.last_reject
+    pref.verify_plonk(proof, oracle, pos_consts=(rc, circ, diag), public=public)
+    dw.free()
+    ck.free()
+    broken = [list(f) for f in chain]
+    broken[3][7] = b"\x0a\x20" + bytes(32)                             # the chain's target header names another validator set
+    with pytest.raises(ValueError):
+        gd.combined_skip_circuit(prover, trusted, (tk, tp), broken, (vk, vp), signed, idx, h0, max_skip=1000)
