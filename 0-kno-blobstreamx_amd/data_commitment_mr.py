@@ -65,6 +65,12 @@ class DataCommitmentMapReduce:
     powers of two; the number of leaves must be fan_in^k * m with the last level's fan-in m a power of two <= fan_in (e.g. 64 leaves, fan_in 16:
     4 nodes of 16, then a root of 4)."""
 
+    N_PUBLIC = 12                       # public inputs of every proof of the tree: R (8 words) then D (4 words)
+
+    def _combine_for(self, span):
+        """the node's statement-combining hook; span = how many leaf units (blocks) each child covers at this level"""
+        return _combine
+
     def __init__(self, prover, poseidon_consts, leaf_blocks=64, fan_in=8, num_queries=28, pow_bits=16, map_provers=()):
         """map_provers: further Provers on the same GPU (their Poseidon constants set): the Map step then proves leaves on all of them at once,
         one host thread each (the latency-bound phases of one leaf proof overlap the throughput-bound phases of another, as in mapreduce.py)"""
@@ -131,33 +137,36 @@ class DataCommitmentMapReduce:
         return [p for _, p in done]
 
     # ---- Reduce -------------------------------------------------------------------------------------------------------------------
-    def _node(self, level, proofs, child_key):
+    def _node(self, level, proofs, child_key, span=0):
         vc = importlib.import_module(__package__ + ".verifier_circuit")
-        k = (level, len(proofs))
+        k = (level, len(proofs), span)
         if k not in self.nodes:
             t0 = time.perf_counter()
-            self.nodes[k] = vc.RecursionProgram(self.prover, proofs, child_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80, n_public=12,
-                                                cap_height=1, child_is_recursion=True, child_sha=True, combine=_combine, builder_wires=SHA_GATE_WIRES)
+            self.nodes[k] = vc.RecursionProgram(self.prover, proofs, child_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80,
+                                                n_public=self.N_PUBLIC, cap_height=1, child_is_recursion=True, child_sha=True,
+                                                combine=self._combine_for(span), builder_wires=SHA_GATE_WIRES)
             self.record_seconds[f"node_level{level}_fan{len(proofs)}"] = round(time.perf_counter() - t0, 3)
         return self.nodes[k]
 
-    def reduce(self, proofs, timings=None, child_key=None, level=1):
+    def reduce(self, proofs, timings=None, child_key=None, level=1, span=None):
         """fold child proofs level by level; returns (root proof, its public inputs, its verifying key, the next level number).  child_key /
-        level: where the fold starts (default: leaf proofs at level 1; a later start folds node proofs made elsewhere, e.g. on other ranks)"""
+        level / span: where the fold starts (default: leaf proofs at level 1, each covering leaf_blocks units; a later start folds node proofs made
+        elsewhere, e.g. on other ranks, each covering `span` units)"""
         cur, key, public = list(proofs), (self.leaf_circuit.cap() if child_key is None else child_key), None
+        span = self.leaf_blocks if span is None else span
         while True:
             fan = min(self.fan_in, len(cur))
             if len(cur) % fan or fan & (fan - 1):
                 raise ValueError("the number of proofs at a level is not a multiple of a power-of-two fan-in")
             t0 = time.perf_counter()
-            rp = self._node(level, cur[:fan], key)
+            rp = self._node(level, cur[:fan], key, span)
             groups = [cur[k:k + fan] for k in range(0, len(cur), fan)]
             if len(groups) > 1 and self.map_provers:
                 # several nodes of one level: one host thread per prover, each with its own commitment of the level's (shared) recording
                 from concurrent.futures import ThreadPoolExecutor
-                if (level, fan) not in self.node_replicas:
-                    self.node_replicas[(level, fan)] = [rp.replicate(p) for p in self.map_provers]
-                workers = [rp] + self.node_replicas[(level, fan)]
+                if (level, fan, span) not in self.node_replicas:
+                    self.node_replicas[(level, fan, span)] = [rp.replicate(p) for p in self.map_provers]
+                workers = [rp] + self.node_replicas[(level, fan, span)]
 
                 def work(w):
                     if w:
@@ -174,8 +183,9 @@ class DataCommitmentMapReduce:
             if timings is not None:
                 timings.append({"level": level, "nodes": len(nxt), "fan_in": fan, "rows": rp.stats["rows"],
                                 "seconds_including_first_recording": round(time.perf_counter() - t0, 4)})
-            key, level = rp.key(), level + 1
+            key, level, span = rp.key(), level + 1, span * fan
             if len(nxt) == 1:
+                self.last_span = span
                 return nxt[0], public, key, level
             cur = nxt
 
@@ -199,14 +209,14 @@ class DataCommitmentMapReduce:
             leaves = self.prove_leaves(heights[lo:hi], data_roots[lo:hi])
             state["map_seconds"] = round(time.perf_counter() - t0, 4)
             if per == 1:
-                state.update(key=self.leaf_circuit.cap(), level=1, public=None)
+                state.update(key=self.leaf_circuit.cap(), level=1, public=None, span=self.leaf_blocks)
                 return leaves[0]
             proof, public, key, level = self.reduce(leaves, levels)
-            state.update(key=key, level=level, public=public)
+            state.update(key=key, level=level, public=public, span=self.last_span)
             return proof
 
         def fold_root(nodes):
-            proof, public, key, _ = self.reduce(nodes, levels, child_key=state["key"], level=state["level"])
+            proof, public, key, _ = self.reduce(nodes, levels, child_key=state["key"], level=state["level"], span=state["span"])
             state.update(key=key, public=public)
             return proof
         t0 = time.perf_counter()
@@ -258,3 +268,180 @@ class DataCommitmentMapReduce:
             self.map_circuits = []
             self.leaf_circuit.free()
             self.leaf_circuit = self.leaf_program = None
+
+
+# ---- the header-chain form as a MapReduce ([RECALLED] blobstreamx: the data commitment is proved over HEADERS walked from a trusted hash) --------
+def _varint_groups(value, n_groups):
+    groups = [(int(value) >> (7 * j)) & 0x7F for j in range(n_groups)]
+    if int(value) >> (7 * n_groups) or (n_groups > 1 and groups[-1] == 0):
+        raise ValueError(f"height {value} does not encode in exactly {n_groups} varint bytes")
+    return groups
+
+
+def _chain_leaf_statement(b, g, start_hash_words, first_height, headers, n_groups):
+    """one leaf of the chain MapReduce on builder b: `headers` (field encodings) follow a header whose hash is start_hash (INPUT words); header k
+    sits at height first_height + k (a variable + constant; its Int64Value field encoding is built in-circuit from range-checked 7-bit groups, whose
+    number n_groups is a constant of the circuit), links to its predecessor's hash through last_block_id, and its data_hash feeds tuple k.
+    Returns the leaf's public inputs: start hash (8), end hash (8), subtree root R (8), first height (1)."""
+    from .gadgets import header_hash_statement
+    start = [b.range32(b.var(v)) for v in start_hash_words]
+    first = b.var(first_height)
+    wrap = lambda ws: [b.constant(0x0a), b.constant(0x20)] + [x for w in ws for x in g.bytes_of_word(w)]
+    c128 = b.constant(128)
+    prev, leaves = start, []
+    for k, fields in enumerate(headers):
+        if len(bytes(fields[4])) < 34 or len(bytes(fields[6])) != 34:
+            raise ValueError("header fields 4 (last_block_id) / 6 (data_hash) do not have the expected encodings")
+        hk = first if k == 0 else b.arith(0, 1, k, first, first, first)                  # first + k
+        gv = []
+        for gval in _varint_groups(b.value(hk), n_groups):
+            v = b.var(gval)
+            b.range32(v)
+            b.range32(b.arith(1, 0, 0, v, b.constant(1 << 25), v))                       # v < 2^7
+            gv.append(v)
+        acc = gv[-1]
+        for v in reversed(gv[:-1]):
+            acc = b.arith(1, 1, 0, acc, c128, v)
+        b.assert_equal(acc, hk)                                                           # the groups spell THIS height
+        # (a canonical varint needs a non-zero top group; a zero one would be a different byte string, hence a different header hash)
+        hfield = [b.constant(0x08)] + [b.arith(0, 1, 0x80, v, v, v) for v in gv[:-1]] + [gv[-1]]
+        data_hash = [g.byte(b.var(v)) for v in bytes(fields[6])[2:]]
+        block_id = wrap(prev) + [g.byte(b.var(v)) for v in bytes(fields[4])[34:]]
+        prev = header_hash_statement(b, g, fields, bound={2: hfield, 4: block_id, 6: [b.constant(0x0a), b.constant(0x20)] + data_hash})
+        lo, hi = b.bit_field(hk, 0, 32), b.bit_field(hk, 32, 17)                         # the height as the low two words of a uint256
+        b.range32(lo)
+        b.range32(hi)
+        b.assert_equal(b.arith(1, 1, 0, hi, g.c2_32, lo), hk)
+        zero = b.constant(0)
+        root_words = [g.word_from_bytes(data_hash[j:j + 4]) for j in range(0, 32, 4)]
+        leaves.append(g.hash_prefixed_64(0x00, [zero] * 6 + [hi, lo] + root_words))
+    while len(leaves) > 1:
+        leaves = [g.hash_prefixed_64(0x01, leaves[j] + leaves[j + 1]) for j in range(0, len(leaves), 2)]
+    return start + prev + leaves[0] + [first]
+
+
+def _chain_leaf_inputs(start_hash, first_height, headers, n_groups):
+    """the recorded leaf program's input vector, in the order _chain_leaf_statement creates its free variables"""
+    out = list(struct.unpack(">8I", bytes(start_hash))) + [int(first_height)]
+    for k, fields in enumerate(headers):
+        out += _varint_groups(first_height + k, n_groups)
+        out += list(bytes(fields[6])[2:])
+        out += list(bytes(fields[4])[34:])
+        for j, fb in enumerate(fields):
+            if j not in (2, 4, 6):
+                out += list(bytes(fb))
+    return out
+
+
+class HeaderChainMapReduce(DataCommitmentMapReduce):
+    """The data commitment of a CHAIN of headers as a MapReduce of proofs: a leaf takes `leaf_headers` consecutive headers (14 field encodings each)
+    after a header whose hash it is given, constrains every link (last_block_id = the predecessor's hash, computed in-circuit), every height field
+    (first_height + k) and hashes the (height, data_hash) tuples into its subtree root; its public inputs are (start hash, end hash, R, first
+    height).  A node verifies its children in-circuit and checks that they are ADJACENT — child k+1 starts at child k's end hash and at
+    first_height + span — before combining the R's with SHA-256 inner nodes: (start of the first, end of the last, R', first height of the first).
+    The root proof therefore says: "walking the headers from start_hash, at heights first_height.., one arrives at end_hash, and their data hashes
+    commit to R".  About 45 compressions per header.  Heights must all encode in `height_varint_bytes` varint bytes (a constant of the circuits)."""
+    N_PUBLIC = 25
+
+    def __init__(self, prover, poseidon_consts, leaf_headers=8, fan_in=8, num_queries=28, pow_bits=16, map_provers=(), height_varint_bytes=4,
+                 field_lengths=(4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22)):
+        super().__init__(prover, poseidon_consts, leaf_blocks=leaf_headers, fan_in=fan_in, num_queries=num_queries, pow_bits=pow_bits,
+                         map_provers=map_provers)
+        self.n_groups, self.field_lengths = height_varint_bytes, tuple(field_lengths)
+
+    def _combine_for(self, span):
+        def combine(b, outs):
+            g = Sha256Rows(b)
+            for left, right in zip(outs, outs[1:]):
+                for x, y in zip(left["public"][8:16], right["public"][:8]):
+                    b.assert_equal(x, y)                                              # right starts where left ended
+                lf = left["public"][24]
+                b.assert_equal(b.arith(0, 1, span, lf, lf, lf), right["public"][24])  # ... and span headers later
+            roots = [o["public"][16:24] for o in outs]
+            while len(roots) > 1:
+                roots = [g.hash_prefixed_64(0x01, roots[k] + roots[k + 1]) for k in range(0, len(roots), 2)]
+            return outs[0]["public"][:8] + outs[-1]["public"][8:16] + roots[0] + [outs[0]["public"][24]]
+        return combine
+
+    def _record_leaf(self):
+        t0 = time.perf_counter()
+        b = CircuitBuilder(self.prover, n_wires=SHA_GATE_WIRES)
+        g = Sha256Rows(b)
+        sample_height = 1 << (7 * (self.n_groups - 1))                                   # the smallest height with this many varint bytes
+        fields = [bytes(n) for n in self.field_lengths]
+        fields[6] = b"\x0a\x20" + bytes(32)
+        for v in _chain_leaf_statement(b, g, [0] * 8, sample_height, [fields] * self.leaf_blocks, self.n_groups):
+            b.public_input(v)
+        self.leaf_program = b.program()
+        self.leaf_circuit = self.leaf_program.setup(self.prover)
+        self.map_circuits = [self.leaf_program.setup(p) for p in self.map_provers]
+        self.record_seconds["leaf"] = round(time.perf_counter() - t0, 3)
+
+    def prove_leaf(self, start_hash, first_height, headers, which=0):
+        if self.leaf_program is None:
+            self._record_leaf()
+        if len(headers) != self.leaf_blocks or any(tuple(len(bytes(f)) for f in h) != self.field_lengths for h in headers):
+            raise ValueError("a leaf takes leaf_headers headers whose field encodings have the recorded lengths")
+        prover, circuit = (self.prover, self.leaf_circuit) if which == 0 else (self.map_provers[which - 1], self.map_circuits[which - 1])
+        vals = self.leaf_program.evaluate(self.consts, _chain_leaf_inputs(start_hash, first_height, headers, self.n_groups), threads=1)
+        dw, public = self.leaf_program.device_witness(prover, vals)
+        try:
+            return circuit.prove_(dw, self.nq, self.pw, public=public), public
+        finally:
+            dw.free()
+
+    @staticmethod
+    def header_hash(fields):
+        """host restatement of a header hash (RFC 6962 root over the field encodings): what links the leaves on the host side"""
+        import hashlib
+
+        def tree(xs):
+            if len(xs) == 1:
+                return hashlib.sha256(b"\x00" + xs[0]).digest()
+            k = 1 << ((len(xs) - 1).bit_length() - 1)
+            return hashlib.sha256(b"\x01" + tree(xs[:k]) + tree(xs[k:])).digest()
+        return tree([bytes(f) for f in fields])
+
+    def prove_chain(self, start_hash, first_height, headers):
+        """headers: the chain after the header with hash start_hash (each header's fields 2 and 4 must already be the real ones: height encoding
+        and last_block_id naming its predecessor — what a node serves).  Returns the prove_range-style dict; public = start hash, end hash,
+        commitment (8 words each), first height."""
+        n, B = len(headers), self.leaf_blocks
+        if n % B:
+            raise ValueError("the chain is not a whole number of leaves")
+        if self.leaf_program is None:
+            self._record_leaf()
+        hashes = [bytes(start_hash)] + [self.header_hash(h) for h in headers]           # host side: the start hash of every leaf
+        t0 = time.perf_counter()
+        jobs = [(hashes[k], first_height + k, headers[k:k + B]) for k in range(0, n, B)]
+        n_workers = 1 + len(self.map_provers)
+        if n_workers == 1 or len(jobs) == 1:
+            leaves = [self.prove_leaf(*j)[0] for j in jobs]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+
+            def work(w):
+                if w:
+                    self.map_provers[w - 1].bind_thread()
+                return [(i, self.prove_leaf(*jobs[i], which=w)[0]) for i in range(w, len(jobs), n_workers)]
+            with ThreadPoolExecutor(n_workers) as ex:
+                done = sorted((p for f in [ex.submit(work, w) for w in range(n_workers)] for p in f.result()), key=lambda t: t[0])
+            leaves = [p for _, p in done]
+        t1 = time.perf_counter()
+        levels = []
+        if len(leaves) == 1:
+            root_proof, key = leaves[0], self.leaf_circuit.cap()
+            public = [int(v) for v in importlib.import_module(__package__).proof_public_inputs(root_proof)]
+        else:
+            root_proof, public, key, _ = self.reduce(leaves, levels)
+        t2 = time.perf_counter()
+        return {"root_proof": root_proof, "public": public, "key": key, "leaves": len(leaves), "map_seconds": round(t1 - t0, 4),
+                "reduce_seconds": round(t2 - t1, 4), "levels": levels, "record_seconds": dict(self.record_seconds),
+                "end_hash": b"".join(struct.pack(">I", v) for v in public[8:16]), "commitment": b"".join(struct.pack(">I", v) for v in public[16:24])}
+
+    def verify_chain(self, root_proof, key, start_hash, end_hash, commitment, first_height):
+        """the consumer: the proof says that the headers walked from start_hash (at heights first_height, first_height + 1, ...) end at end_hash and
+        commit their data hashes to `commitment`; key = the root circuit's verifying key (it fixes the number of headers)"""
+        public = list(struct.unpack(">8I", bytes(start_hash))) + list(struct.unpack(">8I", bytes(end_hash))) + \
+            list(struct.unpack(">8I", bytes(commitment))) + [int(first_height)]
+        return bool(self.prover.plonk_verify(root_proof, key, self.nq, self.pw, public=public))

@@ -102,3 +102,62 @@ def test_data_commitment_of_a_range_by_mapreduce(prover, oracle, pkg):
     assert np.array_equal(key4, out["key"]) and pub4 == out["public"]
     assert mr.verify(root4, key4, heights, roots, out["commitment"])
     mr.free()
+
+
+def _header_chain(rng, bs, dm, start_hash, first, n):
+    lens = (4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22)
+    prev, out = start_hash, []
+    for k in range(n):
+        f = [rng.integers(0, 256, L, dtype=np.uint8).tobytes() for L in lens]
+        f[2] = b"\x08" + bs.encode_varint(first + k)
+        f[4] = b"\x0a\x20" + prev + f[4][34:]
+        f[6] = b"\x0a\x20" + f[6][2:]
+        out.append(f)
+        prev = dm.HeaderChainMapReduce.header_hash(f)
+    return out, prev
+
+
+@pytest.mark.gpu
+def test_header_chain_data_commitment_by_mapreduce(prover, oracle, pkg):
+    """the header-chain form: 8 headers walked from a start hash in 4 leaves of 2, nodes that verify their children in-circuit and check that they
+    are adjacent (hash and height), root = (start hash, end hash, commitment, first height).  The end hash and the commitment equal the hashlib
+    restatement; the proof verifies only for its statement; a second chain replays the recorded programs."""
+    dm = importlib.import_module(graft.PKG_NAME + ".data_commitment_mr")
+    bs = importlib.import_module(graft.PKG_NAME + ".blobstream")
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    rng = np.random.default_rng(4200)
+    start, first = hashlib.sha256(b"trusted header").digest(), 2_500_000
+    headers, end = _header_chain(rng, bs, dm, start, first, 8)
+    mr = dm.HeaderChainMapReduce(prover, consts, leaf_headers=2, fan_in=2, num_queries=6, pow_bits=4)
+    out = mr.prove_chain(start, first, headers)
+    assert out["leaves"] == 4 and [lv["nodes"] for lv in out["levels"]] == [2, 1]
+    want = _root([first + k for k in range(8)], [h[6][2:] for h in headers])
+    assert out["end_hash"] == end and out["commitment"] == want == bs.data_commitment(prover, [first + k for k in range(8)], [h[6][2:] for h in headers])
+    assert out["public"][24] == first and len(out["public"]) == 25
+    assert mr.verify_chain(out["root_proof"], out["key"], start, end, want, first), prover.last_reject
+    pref.verify_plonk(out["root_proof"], oracle, pos_consts=consts, public=out["public"])
+    assert not mr.verify_chain(out["root_proof"], out["key"], start, end, want, first + 1)
+    assert not mr.verify_chain(out["root_proof"], out["key"], end, end, want, first)
+    assert not mr.verify_chain(out["root_proof"], out["key"], start, end, bytes(32), first)
+    # leaves that are not adjacent cannot be folded: swap two leaf proofs
+    l0, _ = mr.prove_leaf(start, first, headers[:2])
+    mid = dm.HeaderChainMapReduce.header_hash(headers[1])
+    l1, _ = mr.prove_leaf(mid, first + 2, headers[2:4])
+    node, public, _, _ = mr.reduce([l0, l1])
+    assert public[:8] == list(struct.unpack(">8I", start)) and public[24] == first
+    with pytest.raises(ValueError):
+        mr.reduce([l1, l0])
+    # a leaf proved with the wrong first height for its headers: its header hashes differ from the real chain's, so it does not connect
+    l1_wrong, _ = mr.prove_leaf(mid, first + 3, headers[2:4])
+    with pytest.raises(ValueError):
+        mr.reduce([l0, l1_wrong])
+    # another chain through the recorded programs
+    rec_before = dict(mr.record_seconds)
+    s2 = hashlib.sha256(b"another").digest()
+    h2, e2 = _header_chain(rng, bs, dm, s2, 3_000_000, 8)
+    out2 = mr.prove_chain(s2, 3_000_000, h2)
+    assert mr.record_seconds == rec_before and out2["end_hash"] == e2 and np.array_equal(out2["key"], out["key"])
+    assert mr.verify_chain(out2["root_proof"], out2["key"], s2, e2, out2["commitment"], 3_000_000)
+    mr.free()
