@@ -71,6 +71,10 @@ class DataCommitmentMapReduce:
         """the node's statement-combining hook; span = how many leaf units (blocks) each child covers at this level"""
         return _combine
 
+    def _child_has_poseidon_rows(self, level):
+        """the circuit flags of the proofs a level-`level` node verifies: here leaves hash their tuples with Poseidon rows, nodes always have them"""
+        return True
+
     def __init__(self, prover, poseidon_consts, leaf_blocks=64, fan_in=8, num_queries=28, pow_bits=16, map_provers=()):
         """map_provers: further Provers on the same GPU (their Poseidon constants set): the Map step then proves leaves on all of them at once,
         one host thread each (the latency-bound phases of one leaf proof overlap the throughput-bound phases of another, as in mapreduce.py)"""
@@ -143,7 +147,7 @@ class DataCommitmentMapReduce:
         if k not in self.nodes:
             t0 = time.perf_counter()
             self.nodes[k] = vc.RecursionProgram(self.prover, proofs, child_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80,
-                                                n_public=self.N_PUBLIC, cap_height=1, child_is_recursion=True, child_sha=True,
+                                                n_public=self.N_PUBLIC, cap_height=1, child_is_recursion=self._child_has_poseidon_rows(level), child_sha=True,
                                                 combine=self._combine_for(span), builder_wires=SHA_GATE_WIRES)
             self.record_seconds[f"node_level{level}_fan{len(proofs)}"] = round(time.perf_counter() - t0, 3)
         return self.nodes[k]
@@ -362,6 +366,9 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
                 roots = [g.hash_prefixed_64(0x01, roots[k] + roots[k + 1]) for k in range(0, len(roots), 2)]
             return outs[0]["public"][:8] + outs[-1]["public"][8:16] + roots[0] + [outs[0]["public"][24]]
         return combine
+
+    def _child_has_poseidon_rows(self, level):
+        return level > 1                                 # chain leaves are SHA rows and arithmetic only; nodes carry the verifier's Poseidon rows
 
     def _record_leaf(self):
         t0 = time.perf_counter()
