@@ -696,6 +696,57 @@ def skip_leg(pkg, n_validators=100):
     return res
 
 
+def header_chain_leg(pkg, n_headers=256, leaf_headers=4, fan_in=8):
+    """the header-chain form of the data commitment as a MapReduce of proofs (data_commitment_mr.HeaderChainMapReduce): n_headers headers walked from a
+    start hash — every last_block_id link, every height field and every data_hash constrained (about 45 SHA-256 compressions per header), nodes that
+    verify their children in-circuit and check adjacency.  BASELINE's CombinedSkip range shape with real statements, minus Ed25519.  N = 1."""
+    import hashlib
+    import importlib
+    dm = importlib.import_module(graft.PKG_NAME + ".data_commitment_mr")
+    bs = importlib.import_module(graft.PKG_NAME + ".blobstream")
+    pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    consts = tuple(np.array(a, dtype=np.uint64) for a in pc.default_constants())
+    provers = [pkg.Prover(0) for _ in range(3)]
+    for p in provers:
+        p.set_poseidon_constants(*consts)
+    rng = np.random.default_rng(21)
+    lens = (4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22)
+
+    def chain(start, first, count):
+        prev, out = start, []
+        for k in range(count):
+            f = [rng.integers(0, 256, L, dtype=np.uint8).tobytes() for L in lens]
+            f[2] = b"\x08" + bs.encode_varint(first + k)
+            f[4] = b"\x0a\x20" + prev + f[4][34:]
+            f[6] = b"\x0a\x20" + f[6][2:]
+            out.append(f)
+            prev = dm.HeaderChainMapReduce.header_hash(f)
+        return out, prev
+    mr = dm.HeaderChainMapReduce(provers[0], consts, leaf_headers=leaf_headers, fan_in=fan_in, map_provers=provers[1:])
+    res = {"headers": n_headers, "leaf_headers": leaf_headers, "fan_in": fan_in, "map_provers_per_gpu": 3}
+    for run in ("first_run_records_circuits", "steady_state"):
+        start, first = hashlib.sha256(run.encode()).digest(), 4_000_000
+        hdrs, end = chain(start, first, n_headers)
+        t0 = time.perf_counter()
+        out = mr.prove_chain(start, first, hdrs)
+        dt = time.perf_counter() - t0
+        lvl = [hashlib.sha256(b"\x00" + int(first + k).to_bytes(32, "big") + hdrs[k][6][2:]).digest() for k in range(n_headers)]
+        while len(lvl) > 1:
+            lvl = [hashlib.sha256(b"\x01" + lvl[i] + lvl[i + 1]).digest() for i in range(0, len(lvl), 2)]
+        ok = out["end_hash"] == end and out["commitment"] == lvl[0] and mr.verify_chain(out["root_proof"], out["key"], start, end, lvl[0], first)
+        res[run] = {"seconds": round(dt, 3), "map_seconds": out["map_seconds"], "reduce_seconds": out["reduce_seconds"],
+                    "end_hash_and_commitment_match_hashlib_and_verify": bool(ok), "headers_per_second": round(n_headers / dt, 1),
+                    "root_proof_bytes": len(out["root_proof"])}
+    res["record_seconds"] = dict(mr.record_seconds)
+    res["leaf"] = {k: v for k, v in mr.leaf_program.stats.items() if k in ("rows", "rows_used", "sha_rows")}
+    res["note"] = ("build-defined statement (NOT upstream's circuit): public inputs of the root proof = start header hash, end header hash, data commitment, "
+                   "first height; header encodings are opaque byte strings of fixed lengths except the three fields the circuit binds")
+    mr.free()
+    for p in provers:
+        p.close()
+    return res
+
+
 def data_commitment_range_leg(pkg, rank, local_rank, world, blocks=4096, leaf_blocks=64, fan_in=8):
     """BASELINE configs[4] shape with a statement that MEANS something: the data commitment of a 4096-block range proved as a MapReduce of
     proofs (data_commitment_mr.py) — 64 leaves of 64 blocks on the SHA row gates (rank r proves the r-th contiguous part), each rank folds its
@@ -920,6 +971,10 @@ def main():
             out["skip_circuit"] = skip_leg(pkg)
         except Exception as e:  # noqa: BLE001
             out["skip_circuit"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
+            out["header_chain_range"] = header_chain_leg(pkg)
+        except Exception as e:  # noqa: BLE001
+            out["header_chain_range"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     # Everything below is extra to the contract's metric and runs collectives of its own on every rank.  An exception in a leg is reported in its
     # object; a HANG (a peer lost inside a collective on some fabric this build never ran on) must not cost the line either: after
     # GLP_BENCH_LEG_TIMEOUT seconds (default 600) rank 0 prints what it has, marks the legs as timed out, and every rank leaves.
