@@ -420,20 +420,7 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
             self._record_leaf()
         hashes = [bytes(start_hash)] + [self.header_hash(h) for h in headers]           # host side: the start hash of every leaf
         t0 = time.perf_counter()
-        jobs = [(hashes[k], first_height + k, headers[k:k + B]) for k in range(0, n, B)]
-        n_workers = 1 + len(self.map_provers)
-        if n_workers == 1 or len(jobs) == 1:
-            leaves = [self.prove_leaf(*j)[0] for j in jobs]
-        else:
-            from concurrent.futures import ThreadPoolExecutor
-
-            def work(w):
-                if w:
-                    self.map_provers[w - 1].bind_thread()
-                return [(i, self.prove_leaf(*jobs[i], which=w)[0]) for i in range(w, len(jobs), n_workers)]
-            with ThreadPoolExecutor(n_workers) as ex:
-                done = sorted((p for f in [ex.submit(work, w) for w in range(n_workers)] for p in f.result()), key=lambda t: t[0])
-            leaves = [p for _, p in done]
+        leaves = self._map_chain(hashes, first_height, headers, 0, n)
         t1 = time.perf_counter()
         levels = []
         if len(leaves) == 1:
@@ -445,6 +432,64 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
         return {"root_proof": root_proof, "public": public, "key": key, "leaves": len(leaves), "map_seconds": round(t1 - t0, 4),
                 "reduce_seconds": round(t2 - t1, 4), "levels": levels, "record_seconds": dict(self.record_seconds),
                 "end_hash": b"".join(struct.pack(">I", v) for v in public[8:16]), "commitment": b"".join(struct.pack(">I", v) for v in public[16:24])}
+
+    def _map_chain(self, hashes, first_height, headers, lo, hi):
+        """leaf proofs of headers[lo:hi] (a whole number of leaves), on every prover this object has; hashes[k] = hash of the header BEFORE header k"""
+        B = self.leaf_blocks
+        jobs = [(hashes[k], first_height + k, headers[k:k + B]) for k in range(lo, hi, B)]
+        n_workers = 1 + len(self.map_provers)
+        if n_workers == 1 or len(jobs) == 1:
+            return [self.prove_leaf(*j)[0] for j in jobs]
+        from concurrent.futures import ThreadPoolExecutor
+
+        def work(w):
+            if w:
+                self.map_provers[w - 1].bind_thread()
+            return [(i, self.prove_leaf(*jobs[i], which=w)[0]) for i in range(w, len(jobs), n_workers)]
+        with ThreadPoolExecutor(n_workers) as ex:
+            done = sorted((p for f in [ex.submit(work, w) for w in range(n_workers)] for p in f.result()), key=lambda t: t[0])
+        return [p for _, p in done]
+
+    def prove_chain_distributed(self, start_hash, first_height, headers, device=None, comm=None):
+        """prove_chain with the work spread over the ranks (mapreduce.reduce_tree_distributed): rank r proves and folds the r-th contiguous part of
+        the chain on its own GPU, ONE all-gather of the node proofs, rank 0 folds the root (its nodes check that the parts are adjacent).  Every rank
+        passes the whole chain.  Returns the prove_chain dict on rank 0 (root_proof None elsewhere)."""
+        mrm = importlib.import_module(__package__ + ".mapreduce")
+        rank, world = mrm._world(comm)
+        n, B = len(headers), self.leaf_blocks
+        if n % (B * world):
+            raise ValueError("the chain is not a whole number of leaves per rank")
+        if self.leaf_program is None:
+            self._record_leaf()
+        hashes = [bytes(start_hash)] + [self.header_hash(h) for h in headers]
+        per = n // world
+        state, levels = {}, []
+
+        def fold_local(_):
+            t0 = time.perf_counter()
+            leaves = self._map_chain(hashes, first_height, headers, rank * per, (rank + 1) * per)
+            state["map_seconds"] = round(time.perf_counter() - t0, 4)
+            if len(leaves) == 1:
+                state.update(key=self.leaf_circuit.cap(), level=1, public=None, span=B)
+                return leaves[0]
+            proof, public, key, level = self.reduce(leaves, levels)
+            state.update(key=key, level=level, public=public, span=self.last_span)
+            return proof
+
+        def fold_root(nodes):
+            proof, public, key, _ = self.reduce(nodes, levels, child_key=state["key"], level=state["level"], span=state["span"])
+            state.update(key=key, public=public)
+            return proof
+        t0 = time.perf_counter()
+        out = mrm.reduce_tree_distributed(fold_local, fold_root, [b""] * (per // B), 1 << 18, device=device, comm=comm)
+        root, public = out["root_proof"], state["public"]
+        if root is not None and public is None:
+            public = [int(v) for v in importlib.import_module(__package__).proof_public_inputs(root)]
+        return {"root_proof": root, "public": public, "key": state["key"] if root is not None else None, "leaves": n // B, "ranks": world,
+                "map_seconds": state["map_seconds"], "seconds": round(time.perf_counter() - t0, 4), "levels": levels,
+                "record_seconds": dict(self.record_seconds),
+                "end_hash": b"".join(struct.pack(">I", v) for v in public[8:16]) if root is not None else None,
+                "commitment": b"".join(struct.pack(">I", v) for v in public[16:24]) if root is not None else None}
 
     def verify_chain(self, root_proof, key, start_hash, end_hash, commitment, first_height):
         """the consumer: the proof says that the headers walked from start_hash (at heights first_height, first_height + 1, ...) end at end_hash and

@@ -153,6 +153,17 @@ def test_header_chain_data_commitment_by_mapreduce(prover, oracle, pkg):
     l1_wrong, _ = mr.prove_leaf(mid, first + 3, headers[2:4])
     with pytest.raises(ValueError):
         mr.reduce([l0, l1_wrong])
+    # the distributed form on one rank, and what two ranks would do in turn (each its contiguous half, then the root over the two node proofs)
+    out3 = mr.prove_chain_distributed(start, first, headers)
+    assert out3["end_hash"] == end and out3["commitment"] == want and out3["ranks"] == 1 and np.array_equal(out3["key"], out["key"])
+    hashes = [start] + [dm.HeaderChainMapReduce.header_hash(h) for h in headers]
+    halves = []
+    for r in range(2):
+        lv = mr._map_chain(hashes, first, headers, 4 * r, 4 * r + 4)
+        nd, _, key1, lvl = mr.reduce(lv)
+        halves.append(nd)
+    root4, pub4, key4, _ = mr.reduce(halves, child_key=key1, level=lvl, span=mr.last_span)
+    assert pub4 == out["public"] and np.array_equal(key4, out["key"])
     # another chain through the recorded programs
     rec_before = dict(mr.record_seconds)
     s2 = hashlib.sha256(b"another").digest()
