@@ -550,7 +550,7 @@ class WitnessProgram:
         cell -> variable map (glp_gather_u64), Poseidon rows' advice wires filled by the GPU; returns (buffer, public values)"""
         n = 1 << self.log_n
         res = self._dev.get(id(prover))
-        if res is None:
+        if res is None or res.ptr is None or res.prover is not prover:            # never uploaded, or freed with its prover (Prover.close)
             res = self._dev[id(prover)] = prover.to_device(self.cell_index)
         vals = np.ascontiguousarray(vals, dtype=np.uint64)
         src = prover.to_device(np.concatenate((vals, self.fixed_values)) if self.fixed_values.size else vals)
@@ -566,7 +566,9 @@ class WitnessProgram:
     def release(self, prover=None):
         """free the resident cell maps (of one prover, or all)"""
         for key in [k for k in self._dev if prover is None or k == id(prover)]:
-            self._dev.pop(key).free()
+            buf = self._dev.pop(key)
+            if buf.ptr is not None and getattr(buf.prover, "ctx", None):
+                buf.free()
 
 
 # ---- the Reduce step's aggregation tree -----------------------------------------------------------------------------------------
