@@ -115,11 +115,8 @@ class DataCommitmentMapReduce:
         prover, circuit = (self.prover, self.leaf_circuit) if which == 0 else (self.map_provers[which - 1], self.map_circuits[which - 1])
         inputs = [w for h, r in zip(heights, data_roots) for w in tuple_words(h, r)]
         vals = self.leaf_program.evaluate(self.consts, inputs, threads=1)
-        dw, public = self.leaf_program.device_witness(prover, vals)
-        try:
-            return circuit.prove_(dw, self.nq, self.pw, public=public), public
-        finally:
-            dw.free()
+        dw, public = self.leaf_program.device_witness(prover, vals, reuse=True)          # the program's own buffer: no allocation per leaf
+        return circuit.prove_(dw, self.nq, self.pw, public=public), public
 
     def prove_leaves(self, heights, data_roots):
         """the Map step of a (sub)range: its leaf proofs in order, on every prover this object has"""
@@ -391,11 +388,8 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
             raise ValueError("a leaf takes leaf_headers headers whose field encodings have the recorded lengths")
         prover, circuit = (self.prover, self.leaf_circuit) if which == 0 else (self.map_provers[which - 1], self.map_circuits[which - 1])
         vals = self.leaf_program.evaluate(self.consts, _chain_leaf_inputs(start_hash, first_height, headers, self.n_groups), threads=1)
-        dw, public = self.leaf_program.device_witness(prover, vals)
-        try:
-            return circuit.prove_(dw, self.nq, self.pw, public=public), public
-        finally:
-            dw.free()
+        dw, public = self.leaf_program.device_witness(prover, vals, reuse=True)
+        return circuit.prove_(dw, self.nq, self.pw, public=public), public
 
     @staticmethod
     def header_hash(fields):

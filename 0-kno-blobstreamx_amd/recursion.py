@@ -545,30 +545,50 @@ class WitnessProgram:
             if bad.size:
                 raise ValueError(f"input {int(k[bad[0]])}: word {int(pos[bad[0]])} differs from the index the transcript derives")
 
-    def device_witness(self, prover, vals):
+    def _resident(self, prover):
+        """what stays on the device per prover: the cell -> variable map, the Poseidon / SHA row lists, an upload buffer for the variables and
+        (reuse=True) the wire matrix itself — hipMalloc / hipFree synchronise the WHOLE device, so a witness per proof must not allocate (three
+        provers sharing a GPU would serialise on it)"""
+        r = self._dev.get(id(prover))
+        if r is None or r["cell"].ptr is None or r["cell"].prover is not prover:            # never uploaded, or freed with its prover (Prover.close)
+            r = {"cell": prover.to_device(self.cell_index),
+                 "pos": prover.to_device(self.pos_row_ids) if self.pos_row_ids.size else None,
+                 "sha": prover.to_device(self.sha_row_ids) if self.sha_row_ids.size else None,
+                 "kinds": prover.to_device(self.sha_kinds) if self.sha_kinds.size else None,
+                 "src": DeviceBuffer(prover, max(8, (self.n_values + self.fixed_values.size) * 8)), "wires": None}
+            self._dev[id(prover)] = r
+        return r
+
+    def device_witness(self, prover, vals, reuse=False):
         """variable values -> wire matrix on the device: the values are uploaded (8 bytes per VARIABLE, not per cell) and placed by the resident
-        cell -> variable map (glp_gather_u64), Poseidon rows' advice wires filled by the GPU; returns (buffer, public values)"""
+        cell -> variable map (glp_gather_u64), the Poseidon and SHA rows' derived wires filled by the GPU; returns (buffer, public values).
+        reuse=True: the buffer is the program's own per-prover wire matrix (valid until the next call for this prover; do not free it) — no device
+        allocation per witness."""
         n = 1 << self.log_n
-        res = self._dev.get(id(prover))
-        if res is None or res.ptr is None or res.prover is not prover:            # never uploaded, or freed with its prover (Prover.close)
-            res = self._dev[id(prover)] = prover.to_device(self.cell_index)
+        r = self._resident(prover)
         vals = np.ascontiguousarray(vals, dtype=np.uint64)
-        src = prover.to_device(np.concatenate((vals, self.fixed_values)) if self.fixed_values.size else vals)
-        dw = DeviceBuffer(prover, self.W * n * 8)
-        try:
-            prover.gather(dw, src, vals.size + self.fixed_values.size, res, self.W * n)
-        finally:
-            src.free()
-        prover.poseidon_gate_fill_rows(dw, self.log_n, self.W, self.pos_row_ids)
-        prover.sha_gate_fill_rows(dw, self.log_n, self.W, self.sha_row_ids, self.sha_kinds)
+        r["src"].upload(np.concatenate((vals, self.fixed_values)) if self.fixed_values.size else vals)
+        if reuse:
+            if r["wires"] is None or r["wires"].ptr is None:
+                r["wires"] = DeviceBuffer(prover, self.W * n * 8)
+            dw = r["wires"]
+        else:
+            dw = DeviceBuffer(prover, self.W * n * 8)
+        prover.gather(dw, r["src"], vals.size + self.fixed_values.size, r["cell"], self.W * n)
+        if r["pos"] is not None:
+            prover._chk(prover.lib.glp_poseidon_gate_fill_rows(prover.ctx, dw.ptr, self.log_n, self.W, r["pos"].ptr, self.pos_row_ids.size),
+                        "glp_poseidon_gate_fill_rows")
+        if r["sha"] is not None:
+            prover._chk(prover.lib.glp_sha_gate_fill_rows(prover.ctx, dw.ptr, self.log_n, self.W, r["sha"].ptr, r["kinds"].ptr, self.sha_row_ids.size),
+                        "glp_sha_gate_fill_rows")
         return dw, [int(v) for v in vals[self.public_vars]]
 
     def release(self, prover=None):
-        """free the resident cell maps (of one prover, or all)"""
+        """free what is resident (for one prover, or all)"""
         for key in [k for k in self._dev if prover is None or k == id(prover)]:
-            buf = self._dev.pop(key)
-            if buf.ptr is not None and getattr(buf.prover, "ctx", None):
-                buf.free()
+            for buf in self._dev.pop(key).values():
+                if buf is not None and buf.ptr is not None and getattr(buf.prover, "ctx", None):
+                    buf.free()
 
 
 # ---- the Reduce step's aggregation tree -----------------------------------------------------------------------------------------

@@ -718,19 +718,17 @@ class RecursionProgram:
         other.circuit = self.program.setup(prover)
         return other
 
-    def witness(self, proofs):
+    def witness(self, proofs, reuse=False):
+        """(device wires, public inputs) for a batch; reuse=True: the wires live in the program's own per-prover buffer (do not free)"""
         inputs, ws = self.program.inputs_from_words(proofs)
         vals = self.program.evaluate(self.consts, inputs)
         self.program.check_words(vals, ws)
-        return self.program.device_witness(self.prover, vals)
+        return self.program.device_witness(self.prover, vals, reuse=reuse)
 
     def prove(self, proofs, num_queries=28, pow_bits=16):
         """(root proof, public inputs) for a batch of proofs of the leaf circuit"""
-        dw, public = self.witness(proofs)
-        try:
-            return self.circuit.prove_(dw, num_queries, pow_bits, public=public), public
-        finally:
-            dw.free()
+        dw, public = self.witness(proofs, reuse=True)
+        return self.circuit.prove_(dw, num_queries, pow_bits, public=public), public
 
     def free(self):
         self.program.release(self.prover)
