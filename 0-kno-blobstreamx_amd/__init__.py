@@ -198,6 +198,7 @@ def load_library():
         "glp_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
         "glp_comm_rank": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
         "glp_comm_destroy": (ctypes.c_int, [_vp]),
+        "glp_comm_reserve": (ctypes.c_int, [_vp, ctypes.c_size_t]),
         "glp_allgather_proofs": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp]),
         "glp_allreduce_min_u64": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     }
@@ -437,8 +438,13 @@ class Prover:
         self._chk(self.lib.glp_comm_destroy(self.ctx), "glp_comm_destroy")
         self.comm_rank = self.comm_size = None
 
+    def comm_reserve(self, block_bytes):
+        """staging for exchanges of blocks this large (no collective inside: agree on the outcome before the exchange)"""
+        self._chk(self.lib.glp_comm_reserve(self.ctx, int(block_bytes)), "glp_comm_reserve")
+
     def allgather_bytes(self, block):
-        """every rank passes a block of the SAME length; returns the nranks blocks concatenated in rank order"""
+        """every rank passes a block of the SAME length; returns the nranks blocks concatenated in rank order.  A GlpError from here means
+        the ranks may be out of step: abort the job on every rank."""
         a = np.frombuffer(bytes(block), dtype=np.uint8)
         out = np.empty(a.size * self.comm_size, dtype=np.uint8)
         self._chk(self.lib.glp_allgather_proofs(self.ctx, a.ctypes.data, a.size, out.ctypes.data), "glp_allgather_proofs")

@@ -58,7 +58,30 @@ const Rccl& rccl() {
 struct glp_comm_state {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 0;
+    // staging blocks of the exchange, resident for the communicator's life (hipMalloc, not the pool: they must not depend on what the prover
+    // holds): a collective entry point that has its staging cannot fail locally BEFORE it enters RCCL and leave the peers waiting
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    size_t cap = 0;                  // bytes per rank block that d_in / d_out (x nranks) hold
+    void* d_red = nullptr;           // all-reduce operand (GLP_COMM_REDUCE_WORDS words)
 };
+#define GLP_COMM_REDUCE_WORDS 4096
+#define GLP_COMM_DEFAULT_BLOCK (4u << 20)
+
+static int comm_reserve(glp_ctx* c, size_t block) {
+    glp_comm_state* st = c->comm;
+    if (block <= st->cap) return GLP_OK;
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, block) != hipSuccess || hipMalloc(&b, block * (size_t)st->nranks) != hipSuccess) {
+        if (a) hipFree(a);
+        glp_set_err(c, "glp_comm_reserve: cannot allocate staging for %zu-byte blocks x %d ranks", block, st->nranks);
+        return GLP_E_NOMEM;
+    }
+    if (st->d_in) hipFree(st->d_in);
+    if (st->d_out) hipFree(st->d_out);
+    st->d_in = a; st->d_out = b; st->cap = block;
+    return GLP_OK;
+}
 
 #define GLP_NCCLCHK(c, expr)                                                                       \
     do {                                                                                           \
@@ -91,7 +114,22 @@ extern "C" int glp_comm_init(glp_ctx* c, const uint8_t* id_in, int rank, int nra
     if (r != ncclSuccess) { delete st; glp_set_err(c, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, ncclGetErrorString(r)); return GLP_E_HIP; }
     st->rank = rank; st->nranks = nranks;
     c->comm = st;
+    // staging for the usual payloads now, where a failure is a failed init on this rank (no peer is inside a data collective yet)
+    if (hipMalloc(&st->d_red, GLP_COMM_REDUCE_WORDS * 8) != hipSuccess) { glp_set_err(c, "glp_comm_init: staging allocation failed"); glp_comm_destroy(c); return GLP_E_NOMEM; }
+    int rc = comm_reserve(c, GLP_COMM_DEFAULT_BLOCK);
+    if (rc != GLP_OK) { glp_comm_destroy(c); return rc; }
     return GLP_OK;
+}
+
+// make room for exchanges of `padded_len`-byte blocks WITHOUT entering a collective: ranks that are about to exchange larger blocks than
+// the default (4 MiB) call this first and agree on the result (e.g. through glp_allreduce_min_u64, whose staging always exists), so that
+// no rank can fail locally inside glp_allgather_proofs while its peers wait in RCCL
+extern "C" int glp_comm_reserve(glp_ctx* c, size_t padded_len) {
+    if (!c) return GLP_E_INVALID;
+    GLP_BIND(c);
+    if (!c->comm) { glp_set_err(c, "glp_comm_reserve: no communicator (glp_comm_init)"); return GLP_E_STATE; }
+    GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+    return comm_reserve(c, padded_len);
 }
 
 extern "C" int glp_comm_rank(glp_ctx* c, int* rank, int* nranks) {
@@ -105,10 +143,15 @@ extern "C" int glp_comm_destroy(glp_ctx* c) {
     if (!c) return GLP_E_INVALID;
     if (!c->comm) return GLP_OK;
     GLP_BIND(c);
-    hipStreamSynchronize(c->stream);
-    rccl().CommDestroy(c->comm->comm);
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    const ncclResult_t rd = rccl().CommDestroy(c->comm->comm);
+    if (c->comm->d_in) hipFree(c->comm->d_in);
+    if (c->comm->d_out) hipFree(c->comm->d_out);
+    if (c->comm->d_red) hipFree(c->comm->d_red);
     delete c->comm;
-    c->comm = nullptr;
+    c->comm = nullptr;                                   // the communicator is gone either way; the status says whether it went cleanly
+    if (es != hipSuccess) { glp_set_err(c, "glp_comm_destroy: stream synchronize: %s", hipGetErrorString(es)); return GLP_E_HIP; }
+    if (rd != ncclSuccess) { glp_set_err(c, "glp_comm_destroy: ncclCommDestroy: %s", ncclGetErrorString(rd)); return GLP_E_HIP; }
     return GLP_OK;
 }
 
@@ -120,12 +163,18 @@ extern "C" int glp_allgather_proofs(glp_ctx* c, const uint8_t* h_mine, size_t pa
     if (!c->comm) { glp_set_err(c, "glp_allgather_proofs: no communicator (glp_comm_init)"); return GLP_E_STATE; }
     if (!h_mine || !h_all || padded_len == 0) { glp_set_err(c, "glp_allgather_proofs: bad argument"); return GLP_E_INVALID; }
     const size_t nr = (size_t)c->comm->nranks;
-    GlpPoolBuf d_in(c), d_out(c);
-    GLP_HIPCHK(c, d_in.alloc(padded_len));
-    GLP_HIPCHK(c, d_out.alloc(padded_len * nr));
-    GLP_HIPCHK(c, hipMemcpyAsync(d_in.p, h_mine, padded_len, hipMemcpyHostToDevice, c->stream));
-    GLP_NCCLCHK(c, rccl().AllGather(d_in.p, d_out.p, padded_len, ncclUint8, c->comm->comm, c->stream));
-    GLP_HIPCHK(c, hipMemcpyAsync(h_all, d_out.p, padded_len * nr, hipMemcpyDeviceToHost, c->stream));
+    // Staging is resident (glp_comm_init / glp_comm_reserve).  A block larger than what was reserved grows it here — the one local failure
+    // left before the collective; callers that exchange more than the default reserve first and agree on the result.  Any non-OK return
+    // from this function means the ranks may be out of step: the caller aborts the job on every rank (there is no recovery inside RCCL).
+    if (padded_len > c->comm->cap) {
+        GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
+        int rc = comm_reserve(c, padded_len);
+        if (rc != GLP_OK) return rc;
+    }
+    void *d_in = c->comm->d_in, *d_out = c->comm->d_out;
+    GLP_HIPCHK(c, hipMemcpyAsync(d_in, h_mine, padded_len, hipMemcpyHostToDevice, c->stream));
+    GLP_NCCLCHK(c, rccl().AllGather(d_in, d_out, padded_len, ncclUint8, c->comm->comm, c->stream));
+    GLP_HIPCHK(c, hipMemcpyAsync(h_all, d_out, padded_len * nr, hipMemcpyDeviceToHost, c->stream));
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     return GLP_OK;
 }
@@ -135,12 +184,11 @@ extern "C" int glp_allreduce_min_u64(glp_ctx* c, uint64_t* h_io, size_t n) {
     if (!c) return GLP_E_INVALID;
     GLP_BIND(c);
     if (!c->comm) { glp_set_err(c, "glp_allreduce_min_u64: no communicator (glp_comm_init)"); return GLP_E_STATE; }
-    if (!h_io || n == 0) { glp_set_err(c, "glp_allreduce_min_u64: bad argument"); return GLP_E_INVALID; }
-    GlpPoolBuf d(c);
-    GLP_HIPCHK(c, d.alloc(n * 8));
-    GLP_HIPCHK(c, hipMemcpyAsync(d.p, h_io, n * 8, hipMemcpyHostToDevice, c->stream));
-    GLP_NCCLCHK(c, rccl().AllReduce(d.p, d.p, n, ncclUint64, ncclMin, c->comm->comm, c->stream));
-    GLP_HIPCHK(c, hipMemcpyAsync(h_io, d.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (!h_io || n == 0 || n > GLP_COMM_REDUCE_WORDS) { glp_set_err(c, "glp_allreduce_min_u64: bad argument (1..%d words)", GLP_COMM_REDUCE_WORDS); return GLP_E_INVALID; }
+    void* d = c->comm->d_red;                            // resident since glp_comm_init: nothing can fail locally before the collective
+    GLP_HIPCHK(c, hipMemcpyAsync(d, h_io, n * 8, hipMemcpyHostToDevice, c->stream));
+    GLP_NCCLCHK(c, rccl().AllReduce(d, d, n, ncclUint64, ncclMin, c->comm->comm, c->stream));
+    GLP_HIPCHK(c, hipMemcpyAsync(h_io, d, n * 8, hipMemcpyDeviceToHost, c->stream));
     GLP_HIPCHK(c, hipStreamSynchronize(c->stream));
     return GLP_OK;
 }

@@ -98,11 +98,11 @@ extern "C" int glp_plonk_setup_ex(glp_ctx* c, const glp_circuit_shape* sh, const
     GLP_HIPCHK(c, ck->sigma_vals.alloc((size_t)R * n * 8));
     GLP_HIPCHK(c, hipMemcpyAsync(ck->sigma_vals.p, d_sigma_vals, (size_t)R * n * 8, hipMemcpyDeviceToDevice, c->stream));
     // batch 0 = [the constant columns (6, or 10 with SHA rows), sigma_0 .. sigma_{R-1}]
-    u64* pre_vals = (u64*)glp_pool_alloc(c, (size_t)(n_const + R) * n * 8);
-    if (!pre_vals) return GLP_E_NOMEM;
-    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals, d_const_vals, (size_t)n_const * n * 8, hipMemcpyDeviceToDevice, c->stream));
-    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals + (size_t)n_const * n, d_sigma_vals, (size_t)R * n * 8, hipMemcpyDeviceToDevice, c->stream));
-    int rc = commit_values(c, pre_vals, n_const + R, log_n, ck->rate_bits, ck->cap_h, ck->pre);
+    GlpPoolBuf pre_vals(c);                      // RAII until commit_values adopts it: an error on the way does not strand the block in pool_live
+    if (pre_vals.alloc((size_t)(n_const + R) * n * 8) != hipSuccess) return GLP_E_NOMEM;
+    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals.p, d_const_vals, (size_t)n_const * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    GLP_HIPCHK(c, hipMemcpyAsync(pre_vals.u() + (size_t)n_const * n, d_sigma_vals, (size_t)R * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    int rc = commit_values(c, (u64*)pre_vals.release(), n_const + R, log_n, ck->rate_bits, ck->cap_h, ck->pre);
     if (rc) return rc;
     // 1 / (x - 1) on the LDE domain
     const u64* w_lo = nullptr; const u64* w_hi = nullptr;

@@ -83,8 +83,8 @@ class DataCommitmentMapReduce:
         self.map_provers, self.map_circuits = list(map_provers), []
         self.leaf_blocks, self.fan_in, self.nq, self.pw = leaf_blocks, fan_in, num_queries, pow_bits
         self.leaf_program = self.leaf_circuit = None
-        self.nodes = {}                 # (level, fan-in) -> RecursionProgram
-        self.node_replicas = {}         # (level, fan-in) -> [RecursionProgram on each map prover]
+        self.nodes = {}                 # (level, fan-in, span, child key) -> RecursionProgram
+        self.node_replicas = {}         # id(node program) -> [its replicas on each map prover]
         self.record_seconds = {}
 
     # ---- Map ----------------------------------------------------------------------------------------------------------------------
@@ -140,7 +140,7 @@ class DataCommitmentMapReduce:
     # ---- Reduce -------------------------------------------------------------------------------------------------------------------
     def _node(self, level, proofs, child_key, span=0):
         vc = importlib.import_module(__package__ + ".verifier_circuit")
-        k = (level, len(proofs), span)
+        k = (level, len(proofs), span, bytes(np.ascontiguousarray(child_key, dtype=np.uint64)))      # the child circuit's key is a CONSTANT of the node circuit
         if k not in self.nodes:
             t0 = time.perf_counter()
             self.nodes[k] = vc.RecursionProgram(self.prover, proofs, child_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80,
@@ -165,9 +165,9 @@ class DataCommitmentMapReduce:
             if len(groups) > 1 and self.map_provers:
                 # several nodes of one level: one host thread per prover, each with its own commitment of the level's (shared) recording
                 from concurrent.futures import ThreadPoolExecutor
-                if (level, fan, span) not in self.node_replicas:
-                    self.node_replicas[(level, fan, span)] = [rp.replicate(p) for p in self.map_provers]
-                workers = [rp] + self.node_replicas[(level, fan, span)]
+                if id(rp) not in self.node_replicas:
+                    self.node_replicas[id(rp)] = [rp.replicate(p) for p in self.map_provers]
+                workers = [rp] + self.node_replicas[id(rp)]
 
                 def work(w):
                     if w:
@@ -248,8 +248,16 @@ class DataCommitmentMapReduce:
                 "reduce_seconds": round(t2 - t1, 4), "levels": levels, "record_seconds": dict(self.record_seconds),
                 "commitment": b"".join(struct.pack(">I", v) for v in public[:8])}
 
+    def expected_key(self, n_blocks):
+        """The VERIFIER's own setup: the verifying key of the root circuit for a range of n_blocks, derived on THIS object from a synthetic range
+        of the same shape (the circuits — leaf, every node level — depend on the shape and the parameters only, never on the tuples).  `verify`
+        must be given a key obtained this way (or from a recording the verifier trusts), never one handed over with the proof: a key names the
+        circuit that was run, and a prover-chosen key could name one without, say, the adjacency checks.  Costs one proof of the synthetic range
+        (the circuits are recorded on the way and stay cached for real ranges)."""
+        return self.prove_range(list(range(1, n_blocks + 1)), [bytes(32)] * n_blocks)["key"]
+
     def verify(self, root_proof, key, heights, data_roots, commitment):
-        """the consumer: `commitment` (32 bytes) is the data commitment of exactly these tuples — the proof's public inputs must be the
+        """the consumer: `key` comes from the verifier's own setup (expected_key), not from the prover. `commitment` (32 bytes) is the data commitment of exactly these tuples — the proof's public inputs must be the
         commitment's words followed by the tuples' digest tree, and the proof must verify for `key` (the root circuit's verifying key)"""
         public = list(struct.unpack(">8I", bytes(commitment))) + tuples_digest(self.consts, heights, data_roots, self.leaf_blocks)
         return bool(self.prover.plonk_verify(root_proof, key, self.nq, self.pw, public=public))
@@ -288,7 +296,7 @@ def _chain_leaf_statement(b, g, start_hash_words, first_height, headers, n_group
     start = [b.range32(b.var(v)) for v in start_hash_words]
     first = b.var(first_height)
     wrap = lambda ws: [b.constant(0x0a), b.constant(0x20)] + [x for w in ws for x in g.bytes_of_word(w)]
-    c128 = b.constant(128)
+    c128, c2_15 = b.constant(128), b.constant(1 << 15)
     prev, leaves = start, []
     for k, fields in enumerate(headers):
         if len(bytes(fields[4])) < 34 or len(bytes(fields[6])) != 34:
@@ -312,7 +320,8 @@ def _chain_leaf_statement(b, g, start_hash_words, first_height, headers, n_group
         lo, hi = b.bit_field(hk, 0, 32), b.bit_field(hk, 32, 17)                         # the height as the low two words of a uint256
         b.range32(lo)
         b.range32(hi)
-        b.assert_equal(b.arith(1, 1, 0, hi, g.c2_32, lo), hk)
+        b.range32(b.arith(1, 0, 0, hi, c2_15, hi))                                      # hi < 2^17: hi * 2^32 + lo < 2^49 cannot wrap mod p, so
+        b.assert_equal(b.arith(1, 1, 0, hi, g.c2_32, lo), hk)                            # (hi, lo) is THE split of hk (no hi = 2^32 - 1, lo = hk + 1 alias)
         zero = b.constant(0)
         root_words = [g.word_from_bytes(data_hash[j:j + 4]) for j in range(0, 32, 4)]
         leaves.append(g.hash_prefixed_64(0x00, [zero] * 6 + [hi, lo] + root_words))
@@ -348,6 +357,8 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
                  field_lengths=(4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22)):
         super().__init__(prover, poseidon_consts, leaf_blocks=leaf_headers, fan_in=fan_in, num_queries=num_queries, pow_bits=pow_bits,
                          map_provers=map_provers)
+        if not 1 <= height_varint_bytes <= 7:
+            raise ValueError("heights are below 2^49: at most 7 varint bytes")
         self.n_groups, self.field_lengths = height_varint_bytes, tuple(field_lengths)
 
     def _combine_for(self, span):
@@ -485,8 +496,31 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
                 "end_hash": b"".join(struct.pack(">I", v) for v in public[8:16]) if root is not None else None,
                 "commitment": b"".join(struct.pack(">I", v) for v in public[16:24]) if root is not None else None}
 
+    def synthetic_chain(self, n_headers, first_height=None, start_hash=bytes(32)):
+        """a well-formed chain of the recorded shape (all-zero opaque fields, real height encodings and links): (headers, end hash)"""
+        from .blobstream import encode_varint
+        first = (1 << (7 * (self.n_groups - 1))) if first_height is None else int(first_height)
+        prev, out = bytes(start_hash), []
+        for k in range(n_headers):
+            f = [bytes(n) for n in self.field_lengths]
+            f[2] = b"\x08" + encode_varint(first + k)
+            f[4] = b"\x0a\x20" + prev + bytes(self.field_lengths[4] - 34)
+            f[6] = b"\x0a\x20" + bytes(32)
+            if len(f[2]) != self.field_lengths[2]:
+                raise ValueError("the recorded height field length does not fit these heights")
+            out.append(f)
+            prev = self.header_hash(f)
+        return out, prev
+
+    def expected_key(self, n_headers):
+        """the verifier's own setup (see DataCommitmentMapReduce.expected_key): the root circuit's key for a chain of n_headers, from a synthetic
+        chain of the recorded shape"""
+        first = 1 << (7 * (self.n_groups - 1))
+        headers, _ = self.synthetic_chain(n_headers, first)
+        return self.prove_chain(bytes(32), first, headers)["key"]
+
     def verify_chain(self, root_proof, key, start_hash, end_hash, commitment, first_height):
-        """the consumer: the proof says that the headers walked from start_hash (at heights first_height, first_height + 1, ...) end at end_hash and
+        """the consumer (key: from the verifier's own expected_key, never from the prover): the proof says that the headers walked from start_hash (at heights first_height, first_height + 1, ...) end at end_hash and
         commit their data hashes to `commitment`; key = the root circuit's verifying key (it fixes the number of headers)"""
         public = list(struct.unpack(">8I", bytes(start_hash))) + list(struct.unpack(">8I", bytes(end_hash))) + \
             list(struct.unpack(">8I", bytes(commitment))) + [int(first_height)]

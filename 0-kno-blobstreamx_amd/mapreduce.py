@@ -62,6 +62,16 @@ def allgather_leaf_proofs(local_blobs, n_leaves, padded_len, device=None, comm=N
     rec = HEADER.size + padded_len
     buf = pack_leaves(local_blobs, padded_len, n_rows=per_rank)
     if comm is not None:
+        # staging first (no collective inside), then agree: no rank may fail locally inside the exchange while its peers wait in RCCL
+        ok = 1
+        try:
+            comm.comm_reserve(per_rank * rec)
+        except Exception:  # noqa: BLE001 — reported below, once every rank knows
+            ok = 0
+        if world > 1:
+            ok = int(comm.allreduce_min([ok])[0])
+        if not ok:
+            raise RuntimeError("the exchange's staging could not be allocated on some rank: no leaf proofs were exchanged")
         rows = comm.allgather_bytes(buf.numpy().tobytes()).reshape(world * per_rank, rec)
     else:
         if device is not None:

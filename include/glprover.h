@@ -376,10 +376,15 @@ int glp_tm_merkle_root_var(glp_ctx* ctx, const uint8_t* d_data, uint64_t data_le
 int glp_comm_unique_id(uint8_t* id_out /* GLP_COMM_ID_BYTES */);
 int glp_comm_init(glp_ctx* ctx, const uint8_t* id /* GLP_COMM_ID_BYTES */, int rank, int nranks);
 int glp_comm_rank(glp_ctx* ctx, int* rank, int* nranks);
-int glp_comm_destroy(glp_ctx* ctx);
+int glp_comm_destroy(glp_ctx* ctx);       /* the communicator is gone afterwards either way; non-OK = it did not go cleanly */
+/* Staging for the exchange lives with the communicator (allocated by glp_comm_init for blocks up to 4 MiB), so a collective entry point
+ * cannot fail locally before it enters RCCL and strand its peers.  Ranks about to exchange LARGER blocks call glp_comm_reserve first (no
+ * collective inside) and agree on the result, e.g. through glp_allreduce_min_u64.  Any non-OK return from glp_allgather_proofs /
+ * glp_allreduce_min_u64 means the ranks may be out of step: abort the job on every rank. */
+int glp_comm_reserve(glp_ctx* ctx, size_t padded_len);
 /* every rank passes padded_len bytes (host); h_all receives nranks * padded_len bytes, rank r's block at r * padded_len */
 int glp_allgather_proofs(glp_ctx* ctx, const uint8_t* h_mine, size_t padded_len, uint8_t* h_all);
-/* element-wise minimum over the ranks, in place (the Reduce step's verdicts) */
+/* element-wise minimum over the ranks, in place (the Reduce step's verdicts); n <= 4096 words */
 int glp_allreduce_min_u64(glp_ctx* ctx, uint64_t* h_io, size_t n);
 
 #ifdef __cplusplus

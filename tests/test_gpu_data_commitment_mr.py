@@ -73,6 +73,14 @@ def test_data_commitment_of_a_range_by_mapreduce(prover, oracle, pkg):
     other[3] = bytes(32)
     assert not mr.verify(out["root_proof"], out["key"], heights, other, out["commitment"])
     assert not mr.verify(out["root_proof"], out["key"], heights[::-1], roots[::-1], out["commitment"])
+    # the verifier derives the key itself (expected_key on its own object and ctx), it does not take it from the prover
+    p2 = pkg.Prover(0)
+    p2.set_poseidon_constants(*consts)
+    vr = dm.DataCommitmentMapReduce(p2, consts, leaf_blocks=2, fan_in=2, num_queries=6, pow_bits=4)
+    vkey = vr.expected_key(8)
+    assert np.array_equal(vkey, out["key"]) and vr.verify(out["root_proof"], vkey, heights, roots, out["commitment"])
+    vr.free()
+    p2.close()
     # a second range through the recorded programs (no builder run): leaf + both node levels are replays
     rec_before = dict(mr.record_seconds)
     h2 = [9_000 + 3 * k for k in range(8)]
@@ -164,6 +172,17 @@ def test_header_chain_data_commitment_by_mapreduce(prover, oracle, pkg):
         halves.append(nd)
     root4, pub4, key4, _ = mr.reduce(halves, child_key=key1, level=lvl, span=mr.last_span)
     assert pub4 == out["public"] and np.array_equal(key4, out["key"])
+    # the VERIFIER's key comes from its own setup — another object on another ctx, a synthetic chain of the same shape — never from the prover
+    # (a key handed over with the proof names whatever circuit the prover chose to run)
+    p2 = pkg.Prover(0)
+    p2.set_poseidon_constants(*consts)
+    vr = dm.HeaderChainMapReduce(p2, consts, leaf_headers=2, fan_in=2, num_queries=6, pow_bits=4)
+    vkey = vr.expected_key(8)
+    assert np.array_equal(vkey, out["key"])
+    assert vr.verify_chain(out["root_proof"], vkey, start, end, want, first), p2.last_reject
+    assert not np.array_equal(vr.expected_key(4), vkey)            # a chain of another length is another circuit tower
+    vr.free()
+    p2.close()
     # another chain through the recorded programs
     rec_before = dict(mr.record_seconds)
     s2 = hashlib.sha256(b"another").digest()

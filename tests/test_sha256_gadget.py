@@ -712,3 +712,52 @@ def test_combined_skip_circuit(prover, oracle, pkg):
     broken[3][7] = b"\x0a\x20" + bytes(32)                             # the chain's target header names another validator set
     with pytest.raises(ValueError):
         gd.combined_skip_circuit(prover, trusted, (tk, tp), broken, (vk, vp), signed, idx, h0, max_skip=1000)
+
+
+def test_chain_leaf_height_words_cannot_alias():
+    """the leaf of the header-chain MapReduce hashes abi.encode(height, data_hash) with the height as two 32-bit words (hi, lo)
+    tied to the height variable by hi * 2^32 + lo == height IN THE FIELD.  Without a bound on hi the pair (2^32 - 1, height + 1) satisfies that
+    equation too (it is height + p) and a prover could commit to another tuple.  hi is now shown to be below 2^17, so the sum cannot wrap: the
+    aliased pair cannot be laid down, the honest one can, and the leaf's tuple hash is hashlib's."""
+    graft.load_package()
+    dm = importlib.import_module(graft.PKG_NAME + ".data_commitment_mr")
+    gd, rec, bs = _mods()
+    rng = np.random.default_rng(312)
+    first = 2_500_000
+    lens = (4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22)
+    start = hashlib.sha256(b"trusted").digest()
+
+    def header(k, prev):
+        f = [rng.integers(0, 256, L, dtype=np.uint8).tobytes() for L in lens]
+        f[2] = b"\x08" + bs.encode_varint(first + k)
+        f[4] = b"\x0a\x20" + prev + f[4][34:]
+        f[6] = b"\x0a\x20" + f[6][2:]
+        return f
+    h0 = header(0, start)
+    headers = [h0, header(1, dm.HeaderChainMapReduce.header_hash(h0))]
+
+    def lay_down(alias):
+        b = rec.CircuitBuilder(object(), n_wires=144)
+        if alias:
+            honest = b.bit_field
+
+            def forged(x, shift, bits):
+                if (shift, bits) == (32, 17):
+                    return b.var(0xFFFFFFFF)                              # a malicious prover's free choice instead of the computed field
+                if (shift, bits) == (0, 32) and b.value(x) >= first:
+                    return b.var(b.value(x) + 1)
+                return honest(x, shift, bits)
+            b.bit_field = forged
+        pub = dm._chain_leaf_statement(b, gd.Sha256Rows(b), list(struct.unpack(">8I", start)), first, headers, 4)
+        return b, pub
+    # the forged pair does satisfy the field equation the circuit used to rely on alone ...
+    assert ((0xFFFFFFFF << 32) + first + 1) % P == first
+    # ... and is refused now (the range check of hi * 2^15 sees a value above 32 bits)
+    with pytest.raises(ValueError):
+        lay_down(alias=True)
+    b, pub = lay_down(alias=False)
+    to_bytes = lambda ws: b"".join(struct.pack(">I", b.value(w)) for w in ws)
+    assert to_bytes(pub[16:24]) == _tm_root([first, first + 1], [h[6][2:] for h in headers]) and b.value(pub[24]) == first
+    assert to_bytes(pub[8:16]) == dm.HeaderChainMapReduce.header_hash(headers[1])
+    with pytest.raises(ValueError):
+        dm.HeaderChainMapReduce(object(), poseidon_consts("small"), height_varint_bytes=8)
