@@ -33,7 +33,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # bit for bit against the CPU oracle at the full 128 x 2^20 size, and the line reports whether it ran with it
 EXPECTED_HEADLINE_PLAN = "strip(R=2^10,C=2^3)+finalT(R=2^10,C=2^3)"
 TIMING_PROTOCOL = ("value: wall clock over exactly --steps back-to-back transforms between barrier+synchronize pairs (mean per step, max "
-                   "over ranks); roofline: mean of per-pass HIP-event times over 3-10 profiled transforms; sizes: mean of 10 after 3 warm-ups; "
+                   "over ranks); roofline.achieved: HIP events on the ctx stream around the same --steps transforms (no event between passes); pass_ms_profiling_mode: per-pass HIP-event times, mean over 3-10 transforms with every pass bracketed (slower by the event overhead); sizes: mean of 10 after 3 warm-ups; "
                    "median_ms_of_50_single_launch_timings: SURVEY 8(d) protocol, each transform bracketed by its own HIP events")
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by profiles/summarize_pmc.py --traffic
 
@@ -727,6 +727,7 @@ def header_chain_leg(pkg, rank, local_rank, world, n_headers=256, leaf_headers=4
             prev = dm.HeaderChainMapReduce.header_hash(f)
         return out, prev
     mr = dm.HeaderChainMapReduce(provers[0], consts, leaf_headers=leaf_headers, fan_in=fan_in, map_provers=provers[1:])
+    _maybe_fault("header_chain_range", rank)
     res = {"headers": n_headers, "leaf_headers": leaf_headers, "fan_in": fan_in, "ranks": world, "map_provers_per_gpu": 3}
     for run in ("first_run_records_circuits", "steady_state"):
         start, first = hashlib.sha256(run.encode()).digest(), 4_000_000
@@ -780,6 +781,7 @@ def data_commitment_range_leg(pkg, rank, local_rank, world, blocks=4096, leaf_bl
     for p in extra:
         p.set_poseidon_constants(*consts)
     mr = dm.DataCommitmentMapReduce(pr, consts, leaf_blocks=leaf_blocks, fan_in=fan_in, map_provers=extra)
+    _maybe_fault("data_commitment_range", rank)
     res = {"blocks": blocks, "leaf_blocks": leaf_blocks, "fan_in": fan_in, "ranks": world, "map_provers_per_gpu": 3,
            "sha256_compressions": (2 * blocks - 1) * 2}
     rng = np.random.default_rng(12)                                  # the same range on every rank
@@ -929,7 +931,11 @@ def main():
             acc = ms if acc is None else [a + b for a, b in zip(acc, ms)]
         pr.set_profiling(False)
         pass_ms = [a / reps for a in acc]
-        kern_ms = sum(pass_ms)
+        # roofline.achieved: the pass kernels of one transform, timed by HIP events on the ctx stream around the SAME --steps back-to-back
+        # transforms `value` is taken over (no event between the passes: the kernels run exactly as in the timed region; the stream holds nothing
+        # else, so event time / steps = the summed average launch durations of the pass kernels + their launch gaps).  pass_ms is the split
+        # from the profiling mode, which brackets every pass with its own events and runs ~2 % slower: it apportions, it does not define.
+        kern_ms = ev_ms / args.steps
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "Goldilocks NTT GB/s @ 2^20\u20132^24", "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
@@ -946,8 +952,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": pmc_traffic_bytes(pr.describe_plan(log_n, batch), float(n) * batch),
                          "kernel": "glp_ntt_pass_kernel (all passes of one transform)",
-                         "pass_ms": [round(m, 4) for m in pass_ms],
-                         "pass_gbps": [round(alg_bytes / (m * 1e-3) / 1e9, 1) for m in pass_ms]},
+                         "kernel_ms_per_transform": round(kern_ms, 4),
+                         "pass_ms_profiling_mode": [round(m, 4) for m in pass_ms],
+                         "pass_gbps_profiling_mode": [round(alg_bytes / (m * 1e-3) / 1e9, 1) for m in pass_ms]},
         }
     d.free()
 
@@ -964,82 +971,202 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(log_n)
     pr.close()
-    if rank == 0 and world == 1 and not args.no_prove:
-        # first half of the BASELINE metric, as far as it can be honoured: end-to-end prove time of
-        # the build's own 2^20-row circuit (configs[1] size); the upstream circuits are not in the mount
-        r = prove_bench([(20, 80)], quiet=True)[0]
-        out["prove"] = {"seconds": r["prove_s_best"], "verified": r["verified"], "verify_seconds": r["verify_s"], "circuit": r["circuit"], "log_n": 20, "wires": 80, "proof_bytes": r["proof_bytes"],
-                        "queries": 28, "pow_bits": 16, "stage_ms": r["stage_ms"],
-                        "stage_detail": prove_stage_detail(r["stage_ms"], 20, 80),
-                        "note": "commit wires, Z/partial products, quotient, FRI openings; inputs resident in HBM"}
-    if rank == 0 and world == 1 and not args.no_prove:
-        try:
-            out["data_commitment_circuit"] = data_commitment_leg(pkg)
-        except Exception as e:  # noqa: BLE001
-            out["data_commitment_circuit"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        try:
-            out["validator_set_circuit"] = validator_set_leg(pkg)
-        except Exception as e:  # noqa: BLE001
-            out["validator_set_circuit"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        try:
-            out["skip_circuit"] = skip_leg(pkg)
-        except Exception as e:  # noqa: BLE001
-            out["skip_circuit"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-    # Everything below is extra to the contract's metric and runs collectives of its own on every rank.  An exception in a leg is reported in its
-    # object; a HANG (a peer lost inside a collective on some fabric this build never ran on) must not cost the line either: after
-    # GLP_BENCH_LEG_TIMEOUT seconds (default 600) rank 0 prints what it has, marks the legs as timed out, and every rank leaves.
-    import threading
-    done = threading.Event()
+    # ---- the contract line goes out NOW: metric, roofline, cpu_baseline.  Everything after this point is extra; whatever happens there — an
+    # exception, a peer lost inside a collective on a fabric this build never ran on, a leg that takes too long — cannot cost the record.
+    # The enriched line (same contract fields + the optional legs) is printed again at the end.
+    if rank == 0:
+        print(json.dumps(dict(out, optional_legs="pending: the enriched line follows")), flush=True)
+    if args.no_prove:
+        _finish(world)
+        return
+    legs = LegRunner(rank, world, out)
+    legs.start_watchdog()
 
-    def watchdog():
-        if done.wait(float(os.environ.get("GLP_BENCH_LEG_TIMEOUT", "600"))):
-            return
-        if rank == 0:
-            for _ in range(20):                      # the main thread may be inserting a leg's result right now
-                try:
-                    line = json.dumps(dict(out, optional_legs_timed_out=True))
-                    break
-                except RuntimeError:
-                    time.sleep(0.05)
-            else:
-                line = json.dumps({k: v for k, v in list(out.items()) if k not in ("mapreduce", "data_commitment_range")} | {"optional_legs_timed_out": True})
-            print(line, flush=True)
-        os._exit(0)
-    if world > 1 and not args.no_prove:
-        threading.Thread(target=watchdog, daemon=True).start()
-    if not args.no_prove:
-        # ... and the MapReduce shape of CombinedSkip (configs[2]/[3]): 16 leaf proofs per GPU + one all-gather,
-        # on every rank.  A failure here must not cost the NTT line: it is reported instead.
-        try:
-            mrr = mapreduce_leg(pkg, rank, local_rank, world)
-        except Exception as e:  # noqa: BLE001
-            mrr = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if rank == 0:
-            out["mapreduce"] = mrr
-        # ... and configs[4]'s shape with a real statement: the data commitment of a 4096-block range as a MapReduce of proofs, on every rank
-        # (powers of two up to 64 ranks: the range is 64 leaves).  GLP_BENCH_RANGE=0 skips it.
-        if os.environ.get("GLP_BENCH_RANGE", "1") != "0" and world <= 64 and world & (world - 1) == 0:
-            try:
-                dcr = data_commitment_range_leg(pkg, rank, local_rank, world)
-            except Exception as e:  # noqa: BLE001
-                dcr = {"error": f"{type(e).__name__}: {e}"[:300]}
-            if rank == 0:
-                out["data_commitment_range"] = dcr
-            try:
-                hcr = header_chain_leg(pkg, rank, local_rank, world)
-            except Exception as e:  # noqa: BLE001
-                hcr = {"error": f"{type(e).__name__}: {e}"[:300]}
-            if rank == 0:
-                out["header_chain_range"] = hcr
-    done.set()
+    def prove_leg():
+        # first half of the BASELINE metric, as far as it can be honoured: end-to-end prove time of the build's own 2^20-row circuits
+        # (configs[1] size); the upstream circuits are not in the mount
+        r = prove_bench([(20, 80)], quiet=True)[0]
+        return {"seconds": r["prove_s_best"], "verified": r["verified"], "verify_seconds": r["verify_s"], "circuit": r["circuit"], "log_n": 20,
+                "wires": 80, "proof_bytes": r["proof_bytes"], "queries": 28, "pow_bits": 16, "stage_ms": r["stage_ms"],
+                "stage_detail": prove_stage_detail(r["stage_ms"], 20, 80),
+                "note": "commit wires, Z/partial products, quotient, FRI openings; inputs resident in HBM"}
+    if world == 1:
+        legs.run("prove", prove_leg, estimate_s=15)
+        legs.run("data_commitment_circuit", lambda: data_commitment_leg(pkg), estimate_s=10)
+        legs.run("validator_set_circuit", lambda: validator_set_leg(pkg), estimate_s=5)
+        legs.run("skip_circuit", lambda: skip_leg(pkg), estimate_s=5)
+    # the MapReduce shape of CombinedSkip (configs[2]/[3]) with the build's arithmetic leaf: 16 leaf proofs per GPU + one all-gather, every rank
+    legs.run("mapreduce", lambda: mapreduce_leg(pkg, rank, local_rank, world), collective=True, estimate_s=40)
+    # configs[4]'s shape with a real statement (powers of two up to 64 ranks: the range is 64 leaves).  GLP_BENCH_RANGE=0 skips these.
+    if os.environ.get("GLP_BENCH_RANGE", "1") != "0" and world <= 64 and world & (world - 1) == 0:
+        legs.run("data_commitment_range", lambda: data_commitment_range_leg(pkg, rank, local_rank, world), collective=True, estimate_s=25)
+        legs.run("header_chain_range", lambda: header_chain_leg(pkg, rank, local_rank, world), collective=True, estimate_s=25)
+    legs.finish()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    _finish(world)
+
+
+def _finish(world):
     if world > 1:
-        try:                                             # the line is out: a peer that left early (watchdog) must not turn it into a failure
+        import torch.distributed as dist
+        try:                                             # the line is out: a peer that left early must not turn it into a failure
             dist.barrier()
             dist.destroy_process_group()
         except Exception:  # noqa: BLE001
             pass
+
+
+_FAULT = os.environ.get("GLP_BENCH_INJECT_FAULT", "")      # "<leg>:<rank>[:hang]": rehearsal aid (tests the leg runner, never set by the driver)
+
+
+def _maybe_fault(leg, rank):
+    """called from inside the collective legs: raises (or sleeps forever with ':hang') on the named rank"""
+    parts = _FAULT.split(":")
+    if len(parts) >= 2 and parts[0] == leg and int(parts[1]) == rank:
+        if len(parts) > 2 and parts[2] == "hang":
+            time.sleep(10 ** 6)
+        raise RuntimeError(f"injected fault in {leg} on rank {rank}")
+
+
+class LegRunner:
+    """Runs the optional legs so that none of them can cost the bench record.
+      * every leg is try/except'ed: its object is the result or {"error": ...};
+      * at N > 1 the ranks meet after every collective leg at a STORE barrier (torch.distributed's rendezvous store: host-side, no GPU
+        collective).  A rank whose leg raised still arrives there; if every rank arrives, all are at a clean point and go on with the next leg.
+        If some rank does not arrive within GLP_BENCH_LEG_GRACE seconds of the first failure (it is stuck inside a collective its failed peer
+        never entered), the job is aborted: the 'abort' key is set, every rank's watchdog thread sees it, rank 0 prints the line it has with
+        `optional_legs_aborted`, and every rank leaves with exit code 0 (the contract line is already out);
+      * a total budget (GLP_BENCH_OPTIONAL_BUDGET, default 270 s — the driver allows 600 s for the whole run) and a per-leg limit
+        (GLP_BENCH_LEG_TIMEOUT, default 150 s): a leg is skipped when its estimate does not fit what is left, and a leg still running at its
+        limit is treated as hung (same exit path as an abort, marked `optional_legs_timed_out`).
+    The watchdog only ever prints and exits (os._exit): it never re-execs and starts nothing on the GPU."""
+
+    def __init__(self, rank, world, out):
+        self.rank, self.world, self.out = rank, world, out
+        self.budget = float(os.environ.get("GLP_BENCH_OPTIONAL_BUDGET", "270"))
+        self.leg_limit = float(os.environ.get("GLP_BENCH_LEG_TIMEOUT", "150"))
+        self.grace = float(os.environ.get("GLP_BENCH_LEG_GRACE", "20"))
+        self.t0 = time.monotonic()
+        self.leg_started, self.leg_name, self.seq = None, None, 0
+        self.store = None
+        if world > 1:
+            try:
+                import torch.distributed as dist
+                self.store = dist.distributed_c10d._get_default_store()
+            except Exception:  # noqa: BLE001 — without the store only the time limits protect the line
+                self.store = None
+        import threading
+        self.done = threading.Event()
+        self.lock = threading.Lock()
+
+    def left(self):
+        return self.budget - (time.monotonic() - self.t0)
+
+    # ---- watchdog thread --------------------------------------------------------------------------------------------------------
+    def start_watchdog(self):
+        import threading
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def _leave(self, why):
+        if self.rank == 0:
+            with self.lock:
+                snap = dict(self.out)
+            snap[why[0]] = why[1]
+            try:
+                line = json.dumps(snap)
+            except Exception:  # noqa: BLE001
+                line = json.dumps({k: v for k, v in snap.items() if k in CONTRACT_KEYS} | {why[0]: why[1]})
+            print(line, flush=True)
+        sys.stdout.flush()
+        os._exit(0)
+
+    def _watch(self):
+        while not self.done.wait(0.5):
+            name, started = self.leg_name, self.leg_started
+            if started is not None and time.monotonic() - started > self.leg_limit:
+                self._set_abort(f"leg {name} exceeded {self.leg_limit:.0f} s on rank {self.rank}")
+                self._leave(("optional_legs_timed_out", f"{name}: still running after {self.leg_limit:.0f} s"))
+            if self.left() < -5:
+                self._leave(("optional_legs_timed_out", f"budget of {self.budget:.0f} s spent (in {name})"))
+            why = self._aborted()
+            if why:
+                self._leave(("optional_legs_aborted", why))
+
+    def _set_abort(self, why):
+        if self.store is not None:
+            try:
+                self.store.set("glp_bench_abort", why)
+            except Exception:  # noqa: BLE001
+                pass
+
+    def _aborted(self):
+        if self.store is None:
+            return None
+        try:
+            if self.store.check(["glp_bench_abort"]):
+                return self.store.get("glp_bench_abort").decode(errors="replace")
+        except Exception:  # noqa: BLE001
+            return None
+        return None
+
+    # ---- legs -------------------------------------------------------------------------------------------------------------------
+    def run(self, name, fn, collective=False, estimate_s=10):
+        if self.left() < estimate_s:
+            if self.rank == 0:
+                with self.lock:
+                    self.out[name] = {"skipped": f"{self.left():.0f} s of the optional budget left, the leg needs about {estimate_s} s"}
+            return
+        self.leg_name, self.leg_started = name, time.monotonic()
+        failed = None
+        try:
+            res = fn()
+        except Exception as e:  # noqa: BLE001
+            failed = f"{type(e).__name__}: {e}"[:300]
+            res = {"error": failed}
+        self.leg_started = None
+        if self.rank == 0:
+            with self.lock:
+                self.out[name] = res
+        if collective and self.world > 1:
+            self._meet(name, failed)
+
+    def _meet(self, name, failed):
+        """store barrier after a collective leg; aborts the job when a peer does not arrive after some rank has failed"""
+        if self.store is None:
+            return
+        self.seq += 1
+        key = f"glp_bench_leg{self.seq}"
+        try:
+            if failed:
+                self.store.set(f"{key}_failed", f"rank {self.rank}: {failed}")
+            self.store.add(f"{key}_count", 1)
+            first_failure = None
+            while True:
+                if int(self.store.add(f"{key}_count", 0)) >= self.world:
+                    break
+                if first_failure is None and self.store.check([f"{key}_failed"]):
+                    first_failure = time.monotonic()
+                if first_failure is not None and time.monotonic() - first_failure > self.grace:
+                    why = self.store.get(f"{key}_failed").decode(errors="replace")
+                    self._set_abort(f"{name}: {why}; a peer never left the leg")
+                    time.sleep(3600)                     # the watchdog thread ends the process
+                time.sleep(0.05)
+            if self.rank == 0 and self.store.check([f"{key}_failed"]):
+                with self.lock:
+                    if isinstance(self.out.get(name), dict):
+                        self.out[name].setdefault("failed_on", self.store.get(f"{key}_failed").decode(errors="replace"))
+        except Exception as e:  # noqa: BLE001 — a store error: fall back to the time limits
+            if self.rank == 0:
+                with self.lock:
+                    self.out.setdefault("leg_runner_warnings", []).append(f"{name}: store barrier failed: {e}"[:200])
+
+    def finish(self):
+        self.done.set()
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                 "data", "config", "roofline", "cpu_baseline")
 
 
 if __name__ == "__main__":

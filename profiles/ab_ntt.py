@@ -18,7 +18,7 @@ for r in range(rounds):
                              text=True).stdout.strip().splitlines()
         try:
             d = json.loads(out[-1])
-            print(json.dumps({"round": r, "lib": os.path.basename(lib), "value": d["value"], "pass_ms": d["roofline"]["pass_ms"],
+            print(json.dumps({"round": r, "lib": os.path.basename(lib), "value": d["value"], "pass_ms": d["roofline"]["pass_ms_profiling_mode"],
                               "kernel_gbps": d["roofline"]["achieved"]}), flush=True)
         except Exception as e:  # noqa: BLE001
             print(json.dumps({"round": r, "lib": os.path.basename(lib), "error": str(e), "tail": out[-1:] }), flush=True)
