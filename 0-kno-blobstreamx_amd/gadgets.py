@@ -392,6 +392,35 @@ def skip_statement(b, g, trusted_header_fields, trusted, target_header_fields, t
     return out if blocks is None else out + (blocks,)
 
 
+def _groups7(value):
+    out, p = [], int(value)
+    while True:
+        out.append(p & 0x7F)
+        p >>= 7
+        if not p:
+            return out
+
+
+def skip_statement_inputs(trusted_header_fields, trusted, target_header_fields, target, signed, heights=None):
+    """the input vector of a program recorded from skip_statement, in the order the statement creates its free variables: per trusted validator
+    its 32 key bytes and its power's 7-bit groups, the same per target validator, the flags, (with heights) the two heights' groups, then the
+    bytes of every header field the statement does not bind (trusted: all but 8 and, with heights, 2; target: all but 7 and 2).  The number of
+    groups per power / height and every field length are constants of the recorded circuit: the replay refuses a vector of another length."""
+    out = []
+    for keys, powers in (trusted, target):
+        for key, power in zip(keys, powers):
+            out += list(bytes(key)) + _groups7(power)
+    out += [1 if sg else 0 for sg in signed]
+    if heights is not None:
+        out += _groups7(heights[0]) + _groups7(heights[1])
+    for fields, bound in ((trusted_header_fields, {8}), (target_header_fields, {7})):
+        skip = bound | ({2} if heights is not None else set())
+        for k, fb in enumerate(fields):
+            if k not in skip:
+                out += list(bytes(fb))
+    return out
+
+
 def _height_field(b, g, height):
     """a header's height as a VARIABLE and its field encoding (Int64Value: 0x08 || varint) as byte variables tied to it: the varint's 7-bit groups
     are range-checked witnesses (their number is a constant of the circuit), height = sum g_j * 128^j.  Heights below 2^49."""

@@ -42,6 +42,8 @@ class CircuitBuilder:
         self.seg_bounds = []             # offsets into prog: [start_0, end_0 = start_1, ..., end_last] of the independent segments
         self.input_tags = []             # per free input: caller's tag (e.g. (proof number, word position)) or None
         self.eq_pairs = []               # copy constraints between different variables
+        self.auto_tag_list = None        # when set: untagged free inputs are tagged (auto_tag_list, running position) — a statement laid down next to
+        self._auto_pos = 0               # in-circuit verifiers reads its witness from ONE more word list after the proofs (combined_skip_mr.py)
         self.word_checks = []            # ("const", tag, value) / ("var", tag, variable) / ("bits", tag, [bit variables]): facts about input
         #                                  words that are checked outside the circuit when a recorded program is replayed
 
@@ -54,6 +56,9 @@ class CircuitBuilder:
     def var(self, value, tag=None):
         """a free witness value (an INPUT of the recorded program); tag says where a replay finds it"""
         v = self._new(value)
+        if tag is None and self.auto_tag_list is not None:
+            tag = (self.auto_tag_list, self._auto_pos)
+            self._auto_pos += 1
         self.prog += (1, v, len(self.input_tags))
         self.input_tags.append(tag)
         return v

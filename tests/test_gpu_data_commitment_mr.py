@@ -191,3 +191,29 @@ def test_header_chain_data_commitment_by_mapreduce(prover, oracle, pkg):
     assert mr.record_seconds == rec_before and out2["end_hash"] == e2 and np.array_equal(out2["key"], out["key"])
     assert mr.verify_chain(out2["root_proof"], out2["key"], s2, e2, out2["commitment"], 3_000_000)
     mr.free()
+
+
+@pytest.mark.gpu
+def test_data_commitment_4096_blocks_at_baseline_size(prover, oracle, pkg):
+    """BASELINE configs[4] at its stated size on one GPU: 4096 blocks = 64 leaves of 64 blocks -> 8 nodes -> root (16 382 constrained SHA-256
+    compressions), full parameters; the commitment equals hashlib's and the proof verifies for exactly these tuples."""
+    dm = importlib.import_module(graft.PKG_NAME + ".data_commitment_mr")
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    extra = [pkg.Prover(0) for _ in range(2)]
+    for p in extra:
+        p.set_poseidon_constants(*consts)
+    rng = np.random.default_rng(4096)
+    heights = [5_000_000 + k for k in range(4096)]
+    roots = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in heights]
+    mr = dm.DataCommitmentMapReduce(prover, consts, leaf_blocks=64, fan_in=8, map_provers=extra)
+    out = mr.prove_range(heights, roots)
+    assert out["leaves"] == 64 and [lv["nodes"] for lv in out["levels"]] == [8, 1]
+    assert out["commitment"] == _root(heights, roots)
+    assert mr.verify(out["root_proof"], out["key"], heights, roots, out["commitment"]), prover.last_reject
+    other = list(roots)
+    other[4095] = bytes(32)
+    assert not mr.verify(out["root_proof"], out["key"], heights, other, out["commitment"])
+    mr.free()
+    for p in extra:
+        p.close()

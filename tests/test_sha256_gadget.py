@@ -761,3 +761,41 @@ def test_chain_leaf_height_words_cannot_alias():
     assert to_bytes(pub[8:16]) == dm.HeaderChainMapReduce.header_hash(headers[1])
     with pytest.raises(ValueError):
         dm.HeaderChainMapReduce(object(), poseidon_consts("small"), height_varint_bytes=8)
+
+
+def test_skip_statement_inputs_mirror_the_builder():
+    """the recorded outer circuit of the CombinedSkip MapReduce replays the skip statement from a flat input vector
+    (gadgets.skip_statement_inputs): it must list the free variables in the order skip_statement creates them.  Checked by evaluating the recorded
+    program on that vector (C evaluator) against the builder's own values, for the recording case and for ANOTHER case of the same shape; a case
+    that breaks the 2/3 rule is refused by the evaluator."""
+    gd, rec, bs = _mods()
+    rng = np.random.default_rng(188)
+    tk, tp, vk, vp, idx, signed, hf_t, hf_v = _skip_case(rng)
+    b = rec.CircuitBuilder(_HostPoseidon(), n_wires=144)
+    b.auto_tag_list = 1
+    gd.skip_statement(b, gd.Sha256Rows(b), hf_t, (tk, tp), hf_v, (vk, vp), signed, idx, heights=(5000, 5100), max_skip=1000)
+    b.auto_tag_list = None
+    assert all(t == (1, k) for k, t in enumerate(b.input_tags))
+    prog = b.program()
+    consts = poseidon_consts("small")
+    inp = gd.skip_statement_inputs(hf_t, (tk, tp), hf_v, (vk, vp), signed, heights=(5000, 5100))
+    assert len(inp) == prog.n_inputs
+    assert np.array_equal(prog.evaluate(consts, inp), np.array(b.values, dtype=np.uint64))
+    # through the tagged path, the way RecursionProgram.witness feeds it: word list 0 is a proof (unused here), list 1 the statement's inputs
+    via_tags, _ = prog.inputs_from_words([np.zeros(1, dtype=np.uint64), np.array(inp, dtype=np.uint64)])
+    assert np.array_equal(via_tags, np.array(inp, dtype=np.uint64))
+    # another case of the same shape (other keys, fields, heights with as many varint groups; powers with as many groups)
+    tk2, _, vk2, _, _, _, hf_t2, hf_v2 = _skip_case(rng)
+    for i in range(3):
+        vk2[i] = tk2[i]
+    tp2, vp2 = [999, 901, 799, 51], [701, 599, 501, 399, 101]
+    b2 = rec.CircuitBuilder(_HostPoseidon(), n_wires=144)
+    gd.skip_statement(b2, gd.Sha256Rows(b2), hf_t2, (tk2, tp2), hf_v2, (vk2, vp2), signed, idx, heights=(6000, 6900), max_skip=1000)
+    vals2 = prog.evaluate(consts, gd.skip_statement_inputs(hf_t2, (tk2, tp2), hf_v2, (vk2, vp2), signed, heights=(6000, 6900)))
+    assert np.array_equal(vals2, np.array(b2.values, dtype=np.uint64))
+    # too little signed power: the evaluator refuses (a range-checked difference is not a 32-bit word / a copy constraint fails)
+    with pytest.raises(ValueError):
+        prog.evaluate(consts, gd.skip_statement_inputs(hf_t2, (tk2, tp2), hf_v2, (vk2, vp2), [True, False, False, False, False], heights=(6000, 6900)))
+    # a gap above max_skip is refused too
+    with pytest.raises(ValueError):
+        prog.evaluate(consts, gd.skip_statement_inputs(hf_t2, (tk2, tp2), hf_v2, (vk2, vp2), signed, heights=(6000, 7001)))
