@@ -622,6 +622,48 @@ def data_commitment_leg(pkg, n_blocks=4, n_blocks_rows=64):
     return res
 
 
+def prove_constrained_leg(pkg, blocks=1024):
+    """configs[1] "with constraints that mean something": ONE circuit of 2^20 rows x 144 wires whose rows are SHA-256 row gates — the
+    DataCommitment statement over 1024 blocks (4094 constrained compressions, gadgets.data_commitment_rows_circuit), proved and verified, with
+    the prover's stage timing tree"""
+    import hashlib
+    import importlib
+    pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    gd = importlib.import_module(graft.PKG_NAME + ".gadgets")
+    pr = pkg.Prover(0)
+    pr.set_poseidon_constants(*(np.array(a, dtype=np.uint64) for a in pc.default_constants()))
+    rng = np.random.default_rng(11)
+    hs = [2_000_000 + i for i in range(blocks)]
+    rs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in hs]
+    t0 = time.perf_counter()
+    ck, dw, public, root = gd.data_commitment_rows_circuit(pr, hs, rs)
+    pr.sync()
+    t_build = time.perf_counter() - t0
+    times = []
+    for _ in range(3):
+        t = time.perf_counter()
+        proof = ck.prove_(dw, 28, 16, public=public)
+        times.append(time.perf_counter() - t)
+    t = time.perf_counter()
+    ok = bool(ck.verify(proof, 28, 16, public=public))
+    t_ver = time.perf_counter() - t
+    pr.set_profiling(True)
+    ck.prove_(dw, 28, 16, public=public)
+    stages = dict(pr.last_stage_ms())
+    pr.set_profiling(False)
+    lvl = [hashlib.sha256(b"\x00" + int(h).to_bytes(32, "big") + r).digest() for h, r in zip(hs, rs)]
+    while len(lvl) > 1:
+        lvl = [hashlib.sha256(b"\x01" + lvl[i] + lvl[i + 1]).digest() for i in range(0, len(lvl), 2)]
+    res = {"circuit": "DataCommitment over 1024 blocks on SHA-256 row gates (build-defined; NOT upstream's circuit)", "log_n": ck.log_n,
+           "wires": ck.n_wires, "sha256_compressions": 2 * (2 * blocks - 1), "seconds": round(min(times), 4), "prove_s": [round(x, 4) for x in times],
+           "verified": ok, "verify_seconds": round(t_ver, 4), "commitment_matches_hashlib": root == lvl[0], "proof_bytes": len(proof),
+           "build_circuit_seconds_python": round(t_build, 2), "queries": 28, "pow_bits": 16, "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
+    dw.free()
+    ck.free()
+    pr.close()
+    return res
+
+
 def validator_set_leg(pkg, n_validators=150):
     """the non-cryptographic half of a Tendermint commit check as a circuit (gadgets.validator_set_circuit): validators_hash of n validators
     (variable-length protobuf leaves, RFC 6962 tree) on the SHA row gates + the > 2/3 voting-power rule; Ed25519 signatures are NOT constrained
@@ -757,6 +799,82 @@ def header_chain_leg(pkg, rank, local_rank, world, n_headers=256, leaf_headers=4
         res["note"] = ("build-defined statement (NOT upstream's circuit): public inputs of the root proof = start header hash, end header hash, data "
                        "commitment, first height; header encodings are opaque byte strings of fixed lengths except the three fields the circuit binds")
     mr.free()
+    for p in provers:
+        p.close()
+    return res
+
+
+def combined_skip_leg(pkg, rank, local_rank, world, skips=(128, 1024), n_validators=100, shared=90):
+    """BASELINE configs[2] / configs[3] with the real statement (combined_skip_mr.CombinedSkipMapReduce): CombinedSkip over `skip` headers as a
+    MapReduce with batch = 8 — leaves of 8 headers (links, heights, data hashes constrained: ~46 SHA-256 compressions per header), nodes that
+    verify their children in-circuit and check adjacency, and the outer circuit that verifies the chain's root proof and lays down the
+    light-client skip rules (two validator sets of 100, 90 shared; > 2/3 and > 1/3 power rules; block numbers).  Rank r proves and folds the
+    r-th contiguous part of the chain (skip/8/N leaves per rank), ONE all-gather of node proofs, rank 0 folds the root and proves the outer
+    circuit.  Whole-job seconds: first run (records the circuits with the Python builder) and steady state; every rank must call it."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    cs = importlib.import_module(graft.PKG_NAME + ".combined_skip_mr")
+    dm = importlib.import_module(graft.PKG_NAME + ".data_commitment_mr")
+    pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    consts = tuple(np.array(a, dtype=np.uint64) for a in pc.default_constants())
+    provers = [pkg.Prover(_gpu_index(local_rank)) for _ in range(3)]
+    for p in provers:
+        p.set_poseidon_constants(*consts)
+    dev = torch.device("cuda", local_rank) if (world > 1 and not _rehearsal()) else None
+    chain = dm.HeaderChainMapReduce(provers[0], consts, leaf_headers=8, fan_in=8, map_provers=provers[1:])
+    _maybe_fault("combined_skip", rank)
+    idx = list(range(shared)) + [None] * (n_validators - shared)
+    res = {"batch": 8, "fan_in": 8, "ranks": world, "map_provers_per_gpu": 3, "validators_per_set": n_validators, "shared_validators": shared,
+           "queries": 28, "pow_bits": 16}
+    for skip in skips:
+        leaves = skip // 8
+        if leaves % world or ((leaves // world) & (leaves // world - 1)):
+            if rank == 0:
+                res[f"skip_{skip}"] = {"skipped": f"{leaves} leaves do not split into a power-of-two number per rank over {world} ranks"}
+            continue
+        mr = cs.CombinedSkipMapReduce(provers[0], consts, skip=skip, chain=chain, max_skip=4096)
+        entry = {"headers": skip, "leaves": leaves, "leaves_per_rank": leaves // world}
+        for run in ("first_run_records_circuits", "steady_state"):
+            case = mr.synthetic_case(n_validators, n_validators, idx, trusted_height=4_000_000 + (run == "steady_state"), seed=skip + (run == "steady_state"))
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            out = mr.prove_skip_distributed(*case, device=dev)
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([dt, out["map_seconds"]], dtype=torch.float64, device=_coll_device())
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt, map_s = float(tt[0].item()), float(tt[1].item())
+            else:
+                map_s = out["map_seconds"]
+            if rank == 0:
+                import hashlib
+                tf, _, hdrs, (vk, _vp), signed, _, h0 = case
+                lvl = [hashlib.sha256(b"\x00" + int(h0 + 1 + k).to_bytes(32, "big") + hdrs[k][6][2:]).digest() for k in range(skip)]
+                while len(lvl) > 1:
+                    lvl = [hashlib.sha256(b"\x01" + lvl[i] + lvl[i + 1]).digest() for i in range(0, len(lvl), 2)]
+                gd = importlib.import_module(graft.PKG_NAME + ".gadgets")
+                t1 = time.perf_counter()
+                ok = (out["commitment"] == lvl[0] and out["trusted_hash"] == dm.HeaderChainMapReduce.header_hash(tf)
+                      and out["target_hash"] == dm.HeaderChainMapReduce.header_hash(hdrs[-1])
+                      and mr.verify(out["root_proof"], out["key"], out["trusted_hash"], out["target_hash"], gd.signer_digest_host(consts, vk, signed),
+                                    h0, h0 + skip, lvl[0]))
+                entry[run] = {"seconds": round(dt, 4), "map_seconds_max_over_ranks": round(map_s, 4),
+                              "chain_seconds_rank0": out["chain_seconds"], "outer_seconds": out["outer_seconds"],
+                              "reduce_seconds_rank0": round(out["chain_seconds"] - out["map_seconds"], 4), "levels_on_rank0": out["levels"],
+                              "verified_and_hashes_commitment_match_hashlib": bool(ok), "verify_seconds": round(time.perf_counter() - t1, 4),
+                              "headers_per_second": round(skip / dt, 1), "root_proof_bytes": len(out["root_proof"]), "outer_rows": out["outer_rows"]}
+                entry["record_seconds_rank0"] = out["record_seconds"]
+        if rank == 0:
+            res[f"skip_{skip}"] = entry
+        mr.free()
+    if rank == 0:
+        res["leaf"] = {k: v for k, v in chain.leaf_program.stats.items() if k in ("rows", "rows_used", "sha_rows")}
+        res["note"] = ("build-defined statement (NOT upstream's circuit): public inputs of the final proof = trusted header hash, target header hash, "
+                       "signer digest, trusted block, target block, data commitment; Ed25519 signatures of the flagged validators are NOT constrained "
+                       "(checked natively against the signer digest); seconds = Map + Reduce + outer circuit, whole job, max over ranks")
+    chain.free()
     for p in provers:
         p.close()
     return res
@@ -992,15 +1110,20 @@ def main():
                 "note": "commit wires, Z/partial products, quotient, FRI openings; inputs resident in HBM"}
     if world == 1:
         legs.run("prove", prove_leg, estimate_s=15)
+        legs.run("prove_constrained", lambda: prove_constrained_leg(pkg), estimate_s=15)
+    # the metric's first half: CombinedSkip(128) and CombinedSkip(1024) with the real statement (configs[2]/[3]), then configs[4]'s 4096-block
+    # data commitment — MapReduces of proofs, on every rank (powers of two up to 64 ranks).  GLP_BENCH_RANGE=0 skips them.
+    if os.environ.get("GLP_BENCH_RANGE", "1") != "0" and world <= 64 and world & (world - 1) == 0:
+        legs.run("combined_skip", lambda: combined_skip_leg(pkg, rank, local_rank, world), collective=True, estimate_s=45)
+        legs.run("data_commitment_range", lambda: data_commitment_range_leg(pkg, rank, local_rank, world), collective=True, estimate_s=25)
+        if os.environ.get("GLP_BENCH_HEADER_CHAIN", "0") == "1":      # superseded by combined_skip (same leaves, 4-header form); opt-in
+            legs.run("header_chain_range", lambda: header_chain_leg(pkg, rank, local_rank, world), collective=True, estimate_s=25)
+    # the MapReduce shape with the build's arithmetic leaf: 16 leaf proofs per GPU + one all-gather + the Reduce forms, every rank
+    legs.run("mapreduce", lambda: mapreduce_leg(pkg, rank, local_rank, world), collective=True, estimate_s=40)
+    if world == 1:
         legs.run("data_commitment_circuit", lambda: data_commitment_leg(pkg), estimate_s=10)
         legs.run("validator_set_circuit", lambda: validator_set_leg(pkg), estimate_s=5)
         legs.run("skip_circuit", lambda: skip_leg(pkg), estimate_s=5)
-    # the MapReduce shape of CombinedSkip (configs[2]/[3]) with the build's arithmetic leaf: 16 leaf proofs per GPU + one all-gather, every rank
-    legs.run("mapreduce", lambda: mapreduce_leg(pkg, rank, local_rank, world), collective=True, estimate_s=40)
-    # configs[4]'s shape with a real statement (powers of two up to 64 ranks: the range is 64 leaves).  GLP_BENCH_RANGE=0 skips these.
-    if os.environ.get("GLP_BENCH_RANGE", "1") != "0" and world <= 64 and world & (world - 1) == 0:
-        legs.run("data_commitment_range", lambda: data_commitment_range_leg(pkg, rank, local_rank, world), collective=True, estimate_s=25)
-        legs.run("header_chain_range", lambda: header_chain_leg(pkg, rank, local_rank, world), collective=True, estimate_s=25)
     legs.finish()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -78,6 +78,34 @@ def test_configs1_full_size_proof_verifies(setup, pkg):
     prover.trim_pool()                  # ~20 GB of cached temporaries: give them back before the next test
 
 
+def test_configs1_constrained_sha_rows_2p20(pkg, setup):
+    """BASELINE configs[1] size with constraints that mean something: 2^20 rows x 144 wires of SHA-256 row gates = the DataCommitment statement
+    over 1024 blocks (4094 constrained compressions) in ONE circuit; commitment = hashlib, accepted by the native and the Python verifier for
+    exactly its public inputs"""
+    import hashlib
+    prover, oracle = setup
+    gd = importlib.import_module(graft.PKG_NAME + ".gadgets")
+    rng = np.random.default_rng(1024)
+    hs = [2_000_000 + i for i in range(1024)]
+    rs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in hs]
+    ck, dw, public, root = gd.data_commitment_rows_circuit(prover, hs, rs)
+    assert ck.log_n == 20 and ck.n_wires == 144
+    lvl = [hashlib.sha256(b"\x00" + int(h).to_bytes(32, "big") + r).digest() for h, r in zip(hs, rs)]
+    while len(lvl) > 1:
+        lvl = [hashlib.sha256(b"\x01" + lvl[i] + lvl[i + 1]).digest() for i in range(0, len(lvl), 2)]
+    assert root == lvl[0] and len(public) == 16 * 1024 + 8
+    proof = ck.prove_(dw, 28, 16, public=public)
+    assert ck.verify(proof, 28, 16, public=public), prover.last_reject
+    info = pref.verify_plonk(proof, oracle, pos_consts=poseidon_consts("small"), public=public)
+    assert info["log_n"] == 20
+    other = list(public)
+    other[-1] ^= 1
+    assert not ck.verify(proof, 28, 16, public=other)
+    dw.free()
+    ck.free()
+    prover.trim_pool()
+
+
 def test_configs2_mapreduce_one_gpu(pkg):
     """BASELINE configs[2] shape on one GPU: 3 concurrent provers x 16 leaf proofs of 2^16 x 80, one gather, Reduce"""
     mr = importlib.import_module(graft.PKG_NAME + ".mapreduce")
