@@ -103,6 +103,15 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise GlpError(f"{LIB_PATH} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    # One HIP / HSA runtime per process.  PyTorch bundles its own copies (and its own RCCL, which binds to the HSA runtime by dlopen): if
+    # this library initialises the system runtime FIRST and torch arrives later (mapreduce.py imports it), RCCL ends up on a second,
+    # uninitialised HSA instance — ncclCommInitRank then fails with "no ROCm-capable device is detected" (found on the GPU box by running two
+    # test files alone; the full suite imports torch at collection time, which is why it never showed there).  A Python process that can
+    # import torch therefore does so BEFORE this library is loaded.  Hosts without Python (tests/cpp) have one runtime to begin with.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001 — no torch: nothing to order
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     sig = {
         "glp_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),

@@ -8,9 +8,9 @@
 #error "compile with -DGLP_INST_LOG_R=<6..12>"
 #endif
 
-template <int MODE, bool INV, int LOG_E>
-static hipError_t launch_one(unsigned grid, unsigned block, size_t lds, hipStream_t st, const GlpNttPassArgs& a) {
-    auto kern = glp_ntt_pass_kernel<GLP_INST_LOG_R, MODE, INV, LOG_E>;
+template <int MODE, bool INV, int LOG_E, bool PLAIN>
+static hipError_t launch_kern(unsigned grid, unsigned block, size_t lds, hipStream_t st, const GlpNttPassArgs& a) {
+    auto kern = glp_ntt_pass_kernel<GLP_INST_LOG_R, MODE, INV, LOG_E, PLAIN>;
     static bool attr_done = false;   // one ctx per process per GPU: no concurrent first call
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -19,6 +19,16 @@ static hipError_t launch_one(unsigned grid, unsigned block, size_t lds, hipStrea
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a);
     return hipGetLastError();
+}
+template <int MODE, bool INV, int LOG_E>
+static hipError_t launch_one(unsigned grid, unsigned block, size_t lds, hipStream_t st, const GlpNttPassArgs& a) {
+    if constexpr (MODE != GLP_FINAL_ROWS && LOG_E == 5) {
+        // the PLAIN instantiation whenever no optional feature is asked for (see ntt_kernels.cuh).  Radix-32 work-items only: on the
+        // radix-16 kernels the plain form measured SLOWER (strip 0.83 vs 0.705 ms at 128 x 2^20 under the max-ILP scheduler: gpurun_out r3d)
+        if (glp_ntt_args_plain(a))
+            return launch_kern<MODE, INV, LOG_E, true>(grid, block, lds, st, a);
+    }
+    return launch_kern<MODE, INV, LOG_E, false>(grid, block, lds, st, a);
 }
 
 #define GLP_CAT2(a, b) a##b
@@ -36,11 +46,24 @@ static hipError_t launch_mode(int mode, int inv, unsigned grid, unsigned block, 
     return hipErrorInvalidValue;
 }
 
+#if defined(GLP_INST_E5)
+// the radix-32 work-items (32 elements each, split LDS exchange) are a translation unit of their own: they are compiled with the default
+// scheduler (max-ILP interleaving costs them registers they do not have: 128 VGPRs at four waves per SIMD) — csrc/Makefile
+extern "C" hipError_t GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _e5)(int mode, int inv, unsigned grid, unsigned block, size_t lds,
+                                                                                hipStream_t st, const GlpNttPassArgs* a) {
+    return launch_mode<5>(mode, inv, grid, block, lds, st, a);
+}
+#else
+#if GLP_INST_LOG_R >= 9
+extern "C" hipError_t GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _e5)(int mode, int inv, unsigned grid, unsigned block, size_t lds,
+                                                                                hipStream_t st, const GlpNttPassArgs* a);
+#endif
 extern "C" hipError_t GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R)(int mode, int inv, int log_e, unsigned grid, unsigned block,
                                                                    size_t lds, hipStream_t st, const GlpNttPassArgs* a) {
     if (log_e == 4) return launch_mode<4>(mode, inv, grid, block, lds, st, a);
-#if GLP_INST_LOG_R == 9 || GLP_INST_LOG_R == 10
-    if (log_e == 5) return launch_mode<5>(mode, inv, grid, block, lds, st, a);
+#if GLP_INST_LOG_R >= 9
+    if (log_e == 5) return GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _e5)(mode, inv, grid, block, lds, st, a);
 #endif
     return hipErrorInvalidValue;
 }
+#endif

@@ -91,6 +91,11 @@ struct GlpNttPassArgs {
     const u64* in_col;     // first pass when STRIP: s_k^c at [(k << log_m) | c], folded into the inter-pass twiddle
 };
 
+// the arguments ask for none of the optional features: the PLAIN instantiation serves them (host launcher and the emulation decide alike)
+static inline bool glp_ntt_args_plain(const GlpNttPassArgs& a) {
+    return !a.coset_log && !a.src_coset && !a.in_row && !a.in_col && !a.tw_full && !a.poly_minor && !a.rev;
+}
+
 // LOG_E = log2 of the elements held per work-item (4: radix <= 16 steps, 5: radix <= 32 steps)
 template <int LOG_R, int LOG_E>
 struct GlpSteps {
@@ -130,12 +135,41 @@ GL_HD u32 glp_bitrev32(u32 v, u32 bits) {
 #define GLP_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) u64 name[]
 #endif
 
-template <int LOG_R, int MODE, bool INV, int LOG_E = 4>
-__global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(GlpNttPassArgs a) {
+// SPLIT exchange (radix-32 work-items, every mode but FINAL_ROWS): the tile lives in LDS as 32-bit HALVES — the low words of all elements are
+// exchanged first, then the high words through the same [R][C+1] u32 array.  The LDS footprint per workgroup halves, so a CU holds four
+// workgroups of 32-element work-items instead of two: the radix-32 steps (one tile-twiddle layer and one exchange per 2^10 tile instead of
+// two) run at the occupancy the radix-16 kernel has (round 2 measured them at HALF of it: 0.97 vs 0.71 ms).
+template <int LOG_E, int MODE> struct GlpSplit { static constexpr bool value = (LOG_E == 5 && MODE != GLP_FINAL_ROWS); };
+
+// PLAIN: a natural-order transform without the optional features — no coset blocks (LDE), no input scale, no per-element inter-pass table, no
+// bit-reversed placement, no polynomial-minor tile order.  Those are runtime switches of the general kernel; compiled out, their address
+// arithmetic and live ranges leave the hot kernel (the radix-32 work-items have no registers to spare for them).  The host launches the PLAIN
+// instantiation whenever the arguments allow it (ntt_inst.hip); results are identical by construction.
+// Launch bounds.  Radix-16 work-items: up to 1024 threads, ~122 VGPRs (four waves per SIMD, what two 72 KiB tiles per CU allow anyway).
+// Radix-32 work-items hold 64 VGPRs of data: the strip pass runs 512-thread workgroups at four waves per SIMD (128 VGPRs, a handful of
+// spills); the FINAL_T pass runs 256-thread workgroups (C = 8) at THREE waves per SIMD — 142 VGPRs, no spills, three 37 KiB tiles per CU —
+// which measured 0.50 instead of 0.56 ms at 128 x 2^20 (same-box A/B, profiles/r03_ntt_e5_probe.jsonl).  The planner keeps FINAL_T radix-32
+// tiles at <= 256 threads (ntt_plan.h).
+template <int LOG_E, int MODE> struct GlpBounds {
+    static constexpr int threads = (LOG_E == 5 && MODE == GLP_FINAL_T) ? 256 : 1024;
+    static constexpr int waves = LOG_E == 5 ? (MODE == GLP_FINAL_T ? 3 : 4) : 1;
+};
+template <int LOG_R, int MODE, bool INV, int LOG_E = 4, bool PLAIN = false>
+__global__ void __launch_bounds__((GlpBounds<LOG_E, MODE>::threads), (GlpBounds<LOG_E, MODE>::waves)) glp_ntt_pass_kernel(GlpNttPassArgs a) {
+    static_assert(!PLAIN || MODE != GLP_FINAL_ROWS, "FINAL_ROWS has no plain form");
     using ST = GlpSteps<LOG_R, LOG_E>;
+    const u32 a_coset_log = PLAIN ? 0u : a.coset_log;
+    const u32 a_src_coset = PLAIN ? 0u : a.src_coset;
+    const u64* const a_in_row = PLAIN ? nullptr : a.in_row;
+    const u64* const a_in_col = PLAIN ? nullptr : a.in_col;
+    const u64* const a_tw_full = PLAIN ? nullptr : a.tw_full;
+    const u32 a_poly_minor = PLAIN ? 0u : a.poly_minor;
+    const u32 a_rev = PLAIN ? 0u : a.rev;
     constexpr u32 R = 1u << LOG_R;
     constexpr u32 E = 1u << LOG_E;
+    constexpr bool SPLIT = GlpSplit<LOG_E, MODE>::value;
     GLP_DYN_LDS(lds);
+    u32* const lds32 = reinterpret_cast<u32*>(lds);
 
     const u32 log_c = a.log_c;
     const u32 C = 1u << log_c;
@@ -160,11 +194,11 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
 
     // element offset of (virtual) polynomial v in a buffer of row stride `stride`
     auto poly_off = [&](u64 v, u64 stride, bool blocked) -> u64 {
-        if (!a.coset_log) return v * stride;
-        const u32 kc = (u32)v & ((1u << a.coset_log) - 1u);
-        return (v >> a.coset_log) * stride + (blocked ? ((u64)glp_bitrev32(kc, a.coset_log) << a.log_n) : 0ull);
+        if (!a_coset_log) return v * stride;
+        const u32 kc = (u32)v & ((1u << a_coset_log) - 1u);
+        return (v >> a_coset_log) * stride + (blocked ? ((u64)glp_bitrev32(kc, a_coset_log) << a.log_n) : 0ull);
     };
-    const u32 coset_mask = (1u << a.coset_log) - 1u;
+    const u32 coset_mask = (1u << a_coset_log) - 1u;
 
     // ---- tile geometry -------------------------------------------------------------
     // STRIP: tile -> (poly, hi, lo0); element (row, col) at  hi*R*m + row*m + lo0 + col
@@ -177,7 +211,7 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
         const u32 log_tpp = a.log_n - LOG_R - log_c;              // tiles per polynomial
         u64 poly;
         u32 t;
-        if (a.poly_minor) {
+        if (a_poly_minor) {
             // (tile position, polynomial) with the polynomial varying fastest, keeping the 2^g
             // line-sharing strips adjacent: the per-element twiddle tile is then reused by
             // `batch` consecutive workgroups out of L2
@@ -193,7 +227,7 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
         const u32 hi = t >> log_mc;
         lo0 = (t & ((1u << log_mc) - 1u)) << log_c;
         const u64 off = ((u64)hi << (LOG_R + a.log_m)) + lo0;
-        sbase = poly_off(poly, a.src_poly_stride, a.src_coset != 0) + off;
+        sbase = poly_off(poly, a.src_poly_stride, a_src_coset != 0) + off;
         dbase = poly_off(poly, a.dst_poly_stride, true) + off;
         kcos = (u32)poly & coset_mask;
     } else {
@@ -202,6 +236,24 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
     const u64 total_rows = (u64)a.batch << log_rows;
 
     u64 x[E];
+
+    // geometry of unit g of this work-item in register step T: (column, first tile row, index below the step's digit)
+    auto unit_geom = [&](auto T_, u32 g, u32& col, u32& row0, u32& o_lo) {
+        constexpr int T = decltype(T_)::value;
+        constexpr int q = ST::q(T);
+        constexpr int lsg = ST::log_sigma(T);
+        const u32 u = g * NT + tid;
+        u32 o;
+        if (T == 0 && MODE != GLP_STRIP) {      // lanes along the contiguous NTT axis
+            o = u & ((R >> q) - 1u);
+            col = u >> (LOG_R - q);
+        } else {                                // lanes along the C contiguous columns
+            col = u & (C - 1u);
+            o = u >> log_c;
+        }
+        o_lo = o & ((1u << lsg) - 1u);
+        row0 = ((o >> lsg) << (q + lsg)) | o_lo;
+    };
 
     glp_static_for<0, ST::S>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
@@ -215,18 +267,8 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
         u32 colv[G], row0v[G], olov[G];
         glp_static_for<0, (int)G>([&](auto g_) {
             constexpr int g = decltype(g_)::value;
-            const u32 u = g * NT + tid;
-            u32 col, o;
-            if (first && MODE != GLP_STRIP) {   // lanes along the contiguous NTT axis
-                o = u & ((R >> q) - 1u);
-                col = u >> (LOG_R - q);
-            } else {                            // lanes along the C contiguous columns
-                col = u & (C - 1u);
-                o = u >> log_c;
-            }
-            const u32 o_lo = o & ((1u << lsg) - 1u);
-            const u32 o_hi = o >> lsg;
-            const u32 row0 = (o_hi << (q + lsg)) | o_lo;
+            u32 col, row0, o_lo;
+            unit_geom(t_, (u32)g, col, row0, o_lo);
             colv[g] = col; row0v[g] = row0; olov[g] = o_lo;
             if constexpr (first) {
                 if constexpr (MODE == GLP_STRIP) {
@@ -235,13 +277,13 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                         constexpr int d = decltype(d_)::value;
                         x[g * r + d] = a.src[p + ((u64)(row0 + ((u32)d << lsg)) << a.log_m)];
                     });
-                    if (a.in_row) {
+                    if (a_in_row) {
                         // coset LDE: the input scale.  All r table words are loaded before the first product: written per element
                         // (load, load, wait, multiply) the compiler serialised every pair behind an s_waitcnt vmcnt(0)
                         u64 sc[r];
                         glp_static_for<0, (int)r>([&](auto d_) {
                             constexpr int d = decltype(d_)::value;
-                            sc[d] = a.in_row[(kcos << LOG_R) + row0 + ((u32)d << lsg)];
+                            sc[d] = a_in_row[(kcos << LOG_R) + row0 + ((u32)d << lsg)];
                         });
                         glp_static_for<0, (int)r>([&](auto d_) {
                             constexpr int d = decltype(d_)::value;
@@ -264,17 +306,17 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                         }
                         rr = rho;
                     }
-                    const u64 p = poly_off(poly, a.src_poly_stride, a.src_coset != 0) + ((u64)rr << LOG_R) + row0;
+                    const u64 p = poly_off(poly, a.src_poly_stride, a_src_coset != 0) + ((u64)rr << LOG_R) + row0;
                     const u32 kc = (u32)poly & coset_mask;
                     glp_static_for<0, (int)r>([&](auto d_) {
                         constexpr int d = decltype(d_)::value;
                         x[g * r + d] = active ? a.src[p + ((u32)d << lsg)] : 0ull;
                     });
-                    if (a.in_row) {                                                  // single-pass sizes: m = 1
+                    if (a_in_row) {                                                  // single-pass sizes: m = 1
                         u64 sc[r];
                         glp_static_for<0, (int)r>([&](auto d_) {
                             constexpr int d = decltype(d_)::value;
-                            sc[d] = a.in_row[(kc << LOG_R) + row0 + ((u32)d << lsg)];
+                            sc[d] = a_in_row[(kc << LOG_R) + row0 + ((u32)d << lsg)];
                         });
                         glp_static_for<0, (int)r>([&](auto d_) {
                             constexpr int d = decltype(d_)::value;
@@ -282,13 +324,13 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                         });
                     }
                 }
-            } else {
+            } else if constexpr (!SPLIT) {
                 const u32 base = row0 * ldA + col;
                 glp_static_for<0, (int)r>([&](auto d_) {
                     constexpr int d = decltype(d_)::value;
                     x[g * r + d] = lds[base + ((u32)d << lsg) * ldA];
                 });
-            }
+            }                                   // SPLIT: x was filled by the previous step's exchange
         });
 
         if constexpr (last && MODE == GLP_FINAL_ROWS && !first) __syncthreads();  // A fully read before B is written
@@ -303,7 +345,17 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
         glp_static_for<0, (int)G>([&](auto g_) {
             constexpr int g = decltype(g_)::value;
             const u32 col = colv[g], row0 = row0v[g];
-            if constexpr (!last) {
+            if constexpr (!last && SPLIT) {
+                // the twiddled values stay in registers (digit order) until the two half exchanges below
+                const u32 o_lo = olov[g];
+                u64 v[r];
+                glp_static_for<0, (int)r>([&](auto d_) {
+                    constexpr int d = decltype(d_)::value;
+                    v[d] = x[g * r + glp_bitrev_c(d, q)];
+                    if constexpr (d != 0) v[d] = gl_mul(v[d], a.tw_tile[(o_lo * (u32)d) << ST::low_bits(t)]);
+                });
+                glp_static_for<0, (int)r>([&](auto d_) { x[g * r + decltype(d_)::value] = v[decltype(d_)::value]; });
+            } else if constexpr (!last) {
                 // X[k_t = d] *= w_{r*sigma}^{o_lo * d}  ==  tw_tile[(o_lo*d) << low_bits(t)]
                 const u32 o_lo = olov[g];
                 const u32 base = row0 * ldA + col;
@@ -322,7 +374,7 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                     // inter-pass twiddle X[k] *= w_N^{j' k}, j' = lo0 + col: a geometric progression in d
                     // (two table look-ups + a running product instead of 16 pairs of gathered loads)
                     u64 tw = 1, ratio = 1;
-                    const u64* const twf = a.tw_full;
+                    const u64* const twf = a_tw_full;
                     if (!twf) {
                         const u32 log_N = LOG_R + a.log_m;
                         const u64 jq = (u64)(lo0 + col);
@@ -336,12 +388,12 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                             ratio = gl_mul(a.tw_lo[e1 & 4095u], a.tw_hi[e1 >> 12]);
                         }
                         // the column's share s_k^(lo0 + col) of the input scale commutes with the row transform
-                        if (a.in_col) tw = gl_mul(tw, a.in_col[((u64)kcos << a.log_m) + lo0 + col]);
+                        if (a_in_col) tw = gl_mul(tw, a_in_col[((u64)kcos << a.log_m) + lo0 + col]);
                     }
                     // natural order: row k; bit-reversed: row bitrev(k) = bitrev(k0) + bitrev_q(d)
-                    const u32 orow0 = a.rev ? glp_bitrev32(k0, LOG_R) : k0;
+                    const u32 orow0 = a_rev ? glp_bitrev32(k0, LOG_R) : k0;
                     const u64 p0 = dbase + ((u64)orow0 << a.log_m) + col;
-                    const u32 sh = a.rev ? a.log_m : a.log_m + KS;
+                    const u32 sh = a_rev ? a.log_m : a.log_m + KS;
                     glp_static_for<0, (int)r>([&](auto d_) {
                         constexpr int d = decltype(d_)::value;
                         u64 v = x[g * r + glp_bitrev_c(d, q)];
@@ -351,7 +403,7 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                             v = gl_mul(v, tw);
                             if constexpr (d + 1 < (int)r) tw = gl_mul(tw, ratio);
                         }
-                        const u64 dm = a.rev ? (u64)glp_bitrev_c(d, q) : (u64)d;
+                        const u64 dm = a_rev ? (u64)glp_bitrev_c(d, q) : (u64)d;
                         a.dst[p0 + (dm << sh)] = v;
                     });
                 } else if constexpr (MODE == GLP_FINAL_T) {
@@ -369,19 +421,68 @@ __global__ void __launch_bounds__(LOG_E == 5 ? 512 : 1024) glp_ntt_pass_kernel(G
                         });
                     }
                 } else {
-                    const u32 kb = col * (R + 1u) + (a.rev ? glp_bitrev32(k0, LOG_R) : k0);   // layout B: [col][R+1]
-                    const u32 sh = a.rev ? 0u : (u32)KS;
+                    const u32 kb = col * (R + 1u) + (a_rev ? glp_bitrev32(k0, LOG_R) : k0);   // layout B: [col][R+1]
+                    const u32 sh = a_rev ? 0u : (u32)KS;
                     glp_static_for<0, (int)r>([&](auto d_) {
                         constexpr int d = decltype(d_)::value;
                         u64 v = x[g * r + glp_bitrev_c(d, q)];
                         if (a.scale != 1) v = gl_mul(v, a.scale);
-                        const u32 dm = a.rev ? (u32)glp_bitrev_c(d, q) : (u32)d;
+                        const u32 dm = a_rev ? (u32)glp_bitrev_c(d, q) : (u32)d;
                         lds[kb + (dm << sh)] = v;
                     });
                 }
             }
         });
-        if constexpr (!last || MODE == GLP_FINAL_ROWS) __syncthreads();
+        if constexpr (!last && SPLIT) {
+            // exchange into the NEXT step's geometry, 32 bits at a time: write the low words at this step's positions, read them at the next
+            // step's; then the same for the high words.  A work-item reads (next step) and later writes (end of next step) the same positions,
+            // so only the three barriers inside the exchange are needed.
+            constexpr int q2 = ST::q(t + 1);
+            constexpr u32 r2 = 1u << q2;
+            constexpr int lsg2 = ST::log_sigma(t + 1);
+            constexpr u32 G2 = E / r2;
+            u32 nb[G2];
+            glp_static_for<0, (int)G2>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                u32 col, row0, o_lo;
+                unit_geom(glp_ic<t + 1>{}, (u32)g, col, row0, o_lo);
+                nb[g] = row0 * ldA + col;
+            });
+            u32 lo[E];
+            glp_static_for<0, (int)G>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                const u32 base = row0v[g] * ldA + colv[g];
+                glp_static_for<0, (int)r>([&](auto d_) {
+                    constexpr int d = decltype(d_)::value;
+                    lds32[base + ((u32)d << lsg) * ldA] = (u32)x[g * r + d];
+                });
+            });
+            __syncthreads();
+            glp_static_for<0, (int)G2>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                glp_static_for<0, (int)r2>([&](auto d_) {
+                    constexpr int d = decltype(d_)::value;
+                    lo[g * r2 + d] = lds32[nb[g] + ((u32)d << lsg2) * ldA];
+                });
+            });
+            __syncthreads();
+            glp_static_for<0, (int)G>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                const u32 base = row0v[g] * ldA + colv[g];
+                glp_static_for<0, (int)r>([&](auto d_) {
+                    constexpr int d = decltype(d_)::value;
+                    lds32[base + ((u32)d << lsg) * ldA] = (u32)(x[g * r + d] >> 32);
+                });
+            });
+            __syncthreads();
+            glp_static_for<0, (int)G2>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                glp_static_for<0, (int)r2>([&](auto d_) {
+                    constexpr int d = decltype(d_)::value;
+                    x[g * r2 + d] = gl_make64(lo[g * r2 + d], lds32[nb[g] + ((u32)d << lsg2) * ldA]);
+                });
+            });
+        } else if constexpr (!last || MODE == GLP_FINAL_ROWS) __syncthreads();
     });
 
     if constexpr (MODE == GLP_FINAL_ROWS) {

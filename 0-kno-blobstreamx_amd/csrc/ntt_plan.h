@@ -44,7 +44,7 @@ static inline int glp_default_log_c(int log_r) {
 }
 
 // radix-32 register steps exist (are instantiated) only for the tile sizes they shorten
-static inline int glp_has_e5(int log_r) { return log_r == 9 || log_r == 10; }
+static inline int glp_has_e5(int log_r) { return log_r >= 9 && log_r <= 12; }
 static inline int glp_default_log_e(int log_r) { (void)log_r; return 4; }
 
 // Parse "r:c[:e],r:c[:e],..." (log2 radix : log2 columns [: log2 elements per work-item]);
@@ -91,6 +91,11 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
             for (int i = 0; i < np; i++) lr[i] = base + (i < extra ? 1 : 0);
         }
         for (int i = 0; i < np; i++) { lc[i] = -1; le[i] = -1; }
+        // Round 3: large natural-order batches of 2^20 run both 2^10 tiles on radix-32 work-items (32 * 32: ONE tile-twiddle layer and one
+        // exchange per tile instead of two), 16 columns wide, with the split LDS exchange (ntt_kernels.cuh GlpSplit): -11 % VALU instructions,
+        // 1.255 vs 1.373 ms at 128 x 2^20 in one run (profiles/r03_ntt_e5_probe.jsonl).  Small batches stay on the radix-16 kernels
+        // (2^20 x 1: 49 vs 28 us), and so do bit-reversed / coset transforms (their general kernel has no registers to spare at 32 elements).
+        if (log_n == 20 && !rev && (batch << log_n) >= (1ull << 25)) { lc[0] = 4; lc[1] = 3; le[0] = le[1] = 5; }
     }
     if (np > GLP_MAX_PASSES) return -1;
     pl->npass = np;
@@ -106,7 +111,8 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
         int e = le[i] >= 4 ? le[i] : glp_default_log_e(lr[i]);
         if (e != 4 && !(e == 5 && glp_has_e5(lr[i]))) return -1;
         ps->log_e = e;
-        const int tmin = 6 + e, tmax = 10 + e;              // 64 .. 1024 threads
+        const int tmin = 6 + e;                              // 64 .. 1024 threads; radix-32 FINAL_T tiles: <= 256 (GlpBounds, ntt_kernels.cuh)
+        const int tmax = (e == 5 && ps->mode == GLP_FINAL_T) ? 8 + e : 10 + e;
         int c = lc[i] >= 0 ? lc[i] : glp_default_log_c(lr[i]);
         if (lc[i] < 0) {
             // small batches: prefer more, narrower tiles until the launch fills the chip
@@ -122,7 +128,8 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
         while (c > 0) {
             unsigned long long R = 1ull << lr[i], C = 1ull << c;
             unsigned long long el = R * C + (R > C ? R : C);
-            if (el * 8 <= 160 * 1024) break;
+            const unsigned long long bytes_per = (e == 5 && ps->mode != GLP_FINAL_ROWS) ? 4 : 8;   // split exchange: 32-bit halves (GlpSplit)
+            if (el * bytes_per <= 160 * 1024) break;
             c--;
         }
         if (c + lr[i] < tmin) return -1;
@@ -154,6 +161,8 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
 
 static inline size_t glp_pass_lds_bytes(const GlpPass* ps) {
     unsigned long long R = 1ull << ps->log_r, C = 1ull << ps->log_c;
+    // radix-32 work-items exchange the tile as 32-bit halves (ntt_kernels.cuh, GlpSplit): half the footprint, except FINAL_ROWS (64-bit restaging)
+    if (ps->log_e == 5 && ps->mode != GLP_FINAL_ROWS) return (size_t)(R * (C + 1) * 4);
     unsigned long long a = R * (C + 1), b = (ps->mode == GLP_FINAL_ROWS) ? C * (R + 1) : 0;
     return (size_t)((a > b ? a : b) * 8);
 }

@@ -31,7 +31,7 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the pass structure the default line runs with; tests/test_gpu_configs.py::test_headline_config_bit_exact checks THIS plan
 # bit for bit against the CPU oracle at the full 128 x 2^20 size, and the line reports whether it ran with it
-EXPECTED_HEADLINE_PLAN = "strip(R=2^10,C=2^3)+finalT(R=2^10,C=2^3)"
+EXPECTED_HEADLINE_PLAN = "strip(R=2^10,C=2^4,E=32)+finalT(R=2^10,C=2^3,E=32)"
 TIMING_PROTOCOL = ("value: wall clock over exactly --steps back-to-back transforms between barrier+synchronize pairs (mean per step, max "
                    "over ranks); roofline.achieved: HIP events on the ctx stream around the same --steps transforms (no event between passes); pass_ms_profiling_mode: per-pass HIP-event times, mean over 3-10 transforms with every pass bracketed (slower by the event overhead); sizes: mean of 10 after 3 warm-ups; "
                    "median_ms_of_50_single_launch_timings: SURVEY 8(d) protocol, each transform bracketed by its own HIP events")

@@ -52,10 +52,19 @@ struct EmuBackend {
         auto go = [&](auto mode_, auto inv_) {
             constexpr int MODE = decltype(mode_)::value;
             constexpr bool INV = decltype(inv_)::value != 0;
+            // the PLAIN instantiation under the condition the host launcher uses (ntt_inst.hip)
+            const bool plain = MODE != GLP_FINAL_ROWS && ps.log_e == 5 && glp_ntt_args_plain(a);
+            auto both = [&](auto e_) {
+                constexpr int LE = decltype(e_)::value;
+                if constexpr (MODE != GLP_FINAL_ROWS && LE == 5) {
+                    if (plain) { glp_emu_launch(grid, block, lds, [&] { glp_ntt_pass_kernel<LR, MODE, INV, LE, true>(a); }); return; }
+                }
+                glp_emu_launch(grid, block, lds, [&] { glp_ntt_pass_kernel<LR, MODE, INV, LE, false>(a); });
+            };
             if (ps.log_e == 5) {
-                if constexpr (LR == 9 || LR == 10) glp_emu_launch(grid, block, lds, [&] { glp_ntt_pass_kernel<LR, MODE, INV, 5>(a); });
+                if constexpr (LR >= 9) both(glp_ic<5>{});
             } else {
-                glp_emu_launch(grid, block, lds, [&] { glp_ntt_pass_kernel<LR, MODE, INV, 4>(a); });
+                both(glp_ic<4>{});
             }
         };
         int key = ps.mode * 2 + (inv ? 1 : 0);

@@ -46,6 +46,10 @@ CASES = [
     # radix-32 register steps (32 elements per work-item)
     (10, 5, 0, 0, "10:2:5", True), (9, 9, 1, 1, "9:3:5", True), (18, 1, 0, 0, "10:3:5,8:4", True),
     (19, 1, 1, 0, "10:2:5,9:3:5", False), (20, 1, 0, 1, "10:3:5,10:3:5", True), (18, 1, 0, 0, "9:3:5,9:3:5", True),
+    # round 3: the split (32-bit halves) LDS exchange of the radix-32 work-items, also on the 2^11 / 2^12 tiles (the two-pass plans of 2^22 / 2^24),
+    # natural order (strip + finalT, PLAIN instantiations), inverse with its scale, several polynomials, and FINAL_ROWS (64-bit restaging)
+    (20, 1, 0, 0, "10:3:5,10:3:5", True), (18, 2, 1, 0, "12:2:5,6:4", False), (18, 1, 0, 0, "6:4,12:3:5", True), (17, 3, 0, 0, "11:3:5,6:3", True),
+    (12, 2, 0, 0, "12:1:5", True), (11, 3, 1, 1, "11:2:5", False), (18, 1, 0, 1, "12:2:5,6:4", True),
 ]
 
 
