@@ -22,6 +22,23 @@ static hipError_t launch_kern(unsigned grid, unsigned block, size_t lds, hipStre
 }
 template <int MODE, bool INV, int LOG_E>
 static hipError_t launch_one(unsigned grid, unsigned block, size_t lds, hipStream_t st, const GlpNttPassArgs& a) {
+    if constexpr (MODE == GLP_STRIP && LOG_E == 5 && GLP_INST_LOG_R == 10) {
+        // the strip kernel of the default plan for large 2^20 batches, tile width as a compile-time constant (LDS offsets as immediates:
+        // 126 VGPRs and no spills instead of 128 + 8 spilled; 0.58 instead of 0.66 ms).  FINAL_T stays on the runtime-width kernel: its
+        // compile-time form needs only 106 VGPRs, runs four waves per SIMD and measured SLOWER (0.53 vs 0.50 ms) than the 142-VGPR form at three
+        constexpr int CTC = 4;
+        if (glp_ntt_args_plain(a) && a.log_c == (unsigned)CTC) {
+            auto kern = glp_ntt_pass_kernel<GLP_INST_LOG_R, MODE, INV, LOG_E, true, CTC>;
+            static bool attr_done_ct = false;
+            if (!attr_done_ct) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr_done_ct = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a);
+            return hipGetLastError();
+        }
+    }
     if constexpr (MODE != GLP_FINAL_ROWS && LOG_E == 5) {
         // the PLAIN instantiation whenever no optional feature is asked for (see ntt_kernels.cuh).  Radix-32 work-items only: on the
         // radix-16 kernels the plain form measured SLOWER (strip 0.83 vs 0.705 ms at 128 x 2^20 under the max-ILP scheduler: gpurun_out r3d)

@@ -150,12 +150,16 @@ template <int LOG_E, int MODE> struct GlpSplit { static constexpr bool value = (
 // spills); the FINAL_T pass runs 256-thread workgroups (C = 8) at THREE waves per SIMD — 142 VGPRs, no spills, three 37 KiB tiles per CU —
 // which measured 0.50 instead of 0.56 ms at 128 x 2^20 (same-box A/B, profiles/r03_ntt_e5_probe.jsonl).  The planner keeps FINAL_T radix-32
 // tiles at <= 256 threads (ntt_plan.h).
-template <int LOG_E, int MODE> struct GlpBounds {
+template <int LOG_E, int MODE, int CT_LOG_C = -1> struct GlpBounds {
+    // (a FINAL_T tile with a compile-time width needs 106 VGPRs: it may run 512 threads at four waves per SIMD)
     static constexpr int threads = (LOG_E == 5 && MODE == GLP_FINAL_T) ? 256 : 1024;
     static constexpr int waves = LOG_E == 5 ? (MODE == GLP_FINAL_T ? 3 : 4) : 1;
 };
-template <int LOG_R, int MODE, bool INV, int LOG_E = 4, bool PLAIN = false>
-__global__ void __launch_bounds__((GlpBounds<LOG_E, MODE>::threads), (GlpBounds<LOG_E, MODE>::waves)) glp_ntt_pass_kernel(GlpNttPassArgs a) {
+// CT_LOG_C >= 0: the tile width is a compile-time constant (the host launches such an instantiation only when a.log_c equals it): every LDS
+// address becomes base + immediate offset — the runtime-width kernel keeps one address VGPR per element and side of the exchange (64 of
+// them on radix-32 work-items: that, not the data, is what spilled).
+template <int LOG_R, int MODE, bool INV, int LOG_E = 4, bool PLAIN = false, int CT_LOG_C = -1>
+__global__ void __launch_bounds__((GlpBounds<LOG_E, MODE, CT_LOG_C>::threads), (GlpBounds<LOG_E, MODE, CT_LOG_C>::waves)) glp_ntt_pass_kernel(GlpNttPassArgs a) {
     static_assert(!PLAIN || MODE != GLP_FINAL_ROWS, "FINAL_ROWS has no plain form");
     using ST = GlpSteps<LOG_R, LOG_E>;
     const u32 a_coset_log = PLAIN ? 0u : a.coset_log;
@@ -171,7 +175,7 @@ __global__ void __launch_bounds__((GlpBounds<LOG_E, MODE>::threads), (GlpBounds<
     GLP_DYN_LDS(lds);
     u32* const lds32 = reinterpret_cast<u32*>(lds);
 
-    const u32 log_c = a.log_c;
+    const u32 log_c = CT_LOG_C >= 0 ? (u32)CT_LOG_C : a.log_c;
     const u32 C = 1u << log_c;
     const u32 NT = (R << log_c) >> LOG_E;    // == blockDim.x (checked on the host)
     const u32 tid = threadIdx.x;
@@ -272,10 +276,13 @@ __global__ void __launch_bounds__((GlpBounds<LOG_E, MODE>::threads), (GlpBounds<
             colv[g] = col; row0v[g] = row0; olov[g] = o_lo;
             if constexpr (first) {
                 if constexpr (MODE == GLP_STRIP) {
-                    const u64 p = sbase + col;
+                    // one per-lane base pointer, then wave-uniform multiples of the row stride (the per-element form
+                    // `(row0 + (d << lsg)) << log_m` cost four VALU instructions per load: or, move, 64-bit shift, 64-bit add)
+                    const u64* const ps = a.src + (sbase + col + ((u64)row0 << a.log_m));
+                    const u64 st = 1ull << (lsg + a.log_m);
                     glp_static_for<0, (int)r>([&](auto d_) {
                         constexpr int d = decltype(d_)::value;
-                        x[g * r + d] = a.src[p + ((u64)(row0 + ((u32)d << lsg)) << a.log_m)];
+                        x[g * r + d] = ps[(u64)d * st];
                     });
                     if (a_in_row) {
                         // coset LDE: the input scale.  All r table words are loaded before the first product: written per element

@@ -50,7 +50,8 @@ def pmc_traffic_bytes(plan_desc, elements):
     mode_id = {"strip": 0, "finalT": 1, "finalRows": 2}
     total = 0.0
     for mode, lr, lc, e32 in re.findall(r"(strip|finalT|finalRows)\(R=2\^(\d+),C=2\^(\d+)(,E=32)?\)", plan_desc):
-        key = f"void glp_ntt_pass_kernel<{lr}, {mode_id[mode]}, false, {5 if e32 else 4}>(GlpNttPassArgs)"
+        key = (f"void glp_ntt_pass_kernel<{lr}, {mode_id[mode]}, false, {5 if e32 else 4}, {'true' if e32 and mode != 'finalRows' else 'false'}>"
+               f"(GlpNttPassArgs)")
         ent = t.get(key)
         if not ent or ent.get("log_c") not in (None, int(lc)):
             return None
@@ -622,6 +623,51 @@ def data_commitment_leg(pkg, n_blocks=4, n_blocks_rows=64):
     return res
 
 
+def prove_cpu_baseline(pkg, log_n=16, W=80, rate_bits=3, cap_h=4):
+    """CPU and GPU side by side for the prove path too.  The wires commitment (inverse transform + coset LDE x 8 + Poseidon
+    Merkle tree: the largest stage of a proof) of a BOUNDED sample — 2^16 rows x 80 wires, 1/16 of the timed proof's stage — by the CPU port
+    (oracle/gl_fast.c::orc_commit_fast, OpenMP on the job's CPU quota) and by the GPU on the same values; the two caps must be equal.
+    kind "port": the in-repo restatement, never the target."""
+    import importlib
+    orc = graft.load_oracle()
+    pc = importlib.import_module(graft.PKG_NAME + ".poseidon_constants")
+    consts = tuple(np.array(a, dtype=np.uint64) for a in pc.default_constants())
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    ptr = lambda a: a.ctypes.data_as(u64p)
+    orc.orc_fast_set_poseidon(*(ptr(a) for a in consts))
+    orc.orc_commit_fast.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64, u64p]
+    orc.orc_commit_fast.restype = ctypes.c_int
+    orc.orc_num_threads.restype = ctypes.c_int
+    orc.orc_set_num_threads.argtypes = [ctypes.c_int]
+    orc.orc_set_num_threads(effective_cpus())
+    cores = orc.orc_num_threads()
+    vals = splitmix_fill(W << log_n, 77).reshape(W, 1 << log_n)
+    pr = pkg.Prover(0)
+    pr.set_poseidon_constants(*consts)
+    pb = pkg.PolynomialBatch.from_values(pr, vals, rate_bits, cap_h)          # warm-up (tables, pool)
+    pb.free()
+    pr.sync()
+    t0 = time.perf_counter()
+    pb = pkg.PolynomialBatch.from_values(pr, vals, rate_bits, cap_h)
+    pr.sync()
+    t_gpu = time.perf_counter() - t0
+    gpu_cap = np.asarray(pb.cap, dtype=np.uint64).reshape(-1).copy()
+    pb.free()
+    pr.close()
+    work, cap = vals.copy(), np.zeros(4 << cap_h, dtype=np.uint64)
+    t0 = time.perf_counter()
+    rc = orc.orc_commit_fast(ptr(work), log_n, W, rate_bits, cap_h, 7, ptr(cap))
+    t_cpu = time.perf_counter() - t0
+    perms = (1 << (log_n + rate_bits)) * ((W + 7) // 8) + (1 << (log_n + rate_bits))
+    return {"stage": "commit_wires", "kind": "port", "cores": cores, "seconds": round(t_cpu, 3), "gpu_seconds_same_sample_incl_h2d": round(t_gpu, 4),
+            "caps_equal": bool(rc == 0 and np.array_equal(cap, gpu_cap)), "poseidon_permutations": perms,
+            "cpu_permutations_per_second": round(perms / t_cpu, 1),
+            "sample": f"wires commitment of 2^{log_n} rows x {W} wires, rate 1/8, cap height {cap_h} (1/16 of the timed proof's commit_wires stage in "
+                      f"rows; the stage is linear in rows up to the transforms' log factor) by oracle/gl_fast.c::orc_commit_fast (hand-reduced "
+                      f"Goldilocks arithmetic, radix-2 transforms, naive-structure Poseidon with 128-bit MDS accumulation; gcc -O3 -march=native, "
+                      f"OpenMP on {cores} threads = the job's CPU quota)"}
+
+
 def prove_constrained_leg(pkg, blocks=1024):
     """configs[1] "with constraints that mean something": ONE circuit of 2^20 rows x 144 wires whose rows are SHA-256 row gates — the
     DataCommitment statement over 1024 blocks (4094 constrained compressions, gadgets.data_commitment_rows_circuit), proved and verified, with
@@ -1106,10 +1152,10 @@ def main():
         r = prove_bench([(20, 80)], quiet=True)[0]
         return {"seconds": r["prove_s_best"], "verified": r["verified"], "verify_seconds": r["verify_s"], "circuit": r["circuit"], "log_n": 20,
                 "wires": 80, "proof_bytes": r["proof_bytes"], "queries": 28, "pow_bits": 16, "stage_ms": r["stage_ms"],
-                "stage_detail": prove_stage_detail(r["stage_ms"], 20, 80),
+                "stage_detail": prove_stage_detail(r["stage_ms"], 20, 80), "cpu_baseline": prove_cpu_baseline(pkg),
                 "note": "commit wires, Z/partial products, quotient, FRI openings; inputs resident in HBM"}
     if world == 1:
-        legs.run("prove", prove_leg, estimate_s=15)
+        legs.run("prove", prove_leg, estimate_s=30)
         legs.run("prove_constrained", lambda: prove_constrained_leg(pkg), estimate_s=15)
     # the metric's first half: CombinedSkip(128) and CombinedSkip(1024) with the real statement (configs[2]/[3]), then configs[4]'s 4096-block
     # data commitment — MapReduces of proofs, on every rank (powers of two up to 64 ranks).  GLP_BENCH_RANGE=0 skips them.

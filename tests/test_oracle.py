@@ -129,3 +129,33 @@ def test_fast_baseline_matches_naive_oracle_at_2_16(oracle):
     oracle.orc_ntt(ptr(a), 16, 3, 0)
     oracle.orc_ntt_fast(ptr(b), 16, 3, 0)
     assert np.array_equal(a, b)
+
+
+def test_fast_commitment_matches_the_naive_composition(oracle):
+    """oracle/gl_fast.c::orc_commit_fast (the prove path's CPU baseline: inverse transform, coset LDE, bit-reversed columns as leaves, Poseidon
+    Merkle tree) against the same stage composed from the NAIVE oracle functions, for a wide batch (sponge), a narrow one (<= 4: the padded leaf
+    itself) and both test constant sets"""
+    from conftest import oracle_merkle, poseidon_consts, rand_field
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    oracle.orc_commit_fast.argtypes = [u64p, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64, u64p]
+    oracle.orc_commit_fast.restype = ctypes.c_int
+    oracle.orc_lde_coset.argtypes = [u64p, u64p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint64]
+    rng = np.random.default_rng(77)
+    for kind, log_n, n_polys, rb, cap_h in (("small", 6, 11, 3, 2), ("big", 5, 3, 2, 1), ("small", 4, 20, 3, 4)):
+        consts = poseidon_consts(kind)
+        oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+        oracle.orc_fast_set_poseidon(*(ptr(a) for a in consts))
+        n, N = 1 << log_n, 1 << (log_n + rb)
+        vals = rand_field(rng, (n_polys, n))
+        coeffs = vals.copy()
+        oracle.orc_ntt(ptr(coeffs), log_n, n_polys, 1)
+        lde = np.zeros((n_polys, N), dtype=np.uint64)
+        oracle.orc_lde_coset(ptr(coeffs), ptr(lde), log_n, rb, n_polys, 7)
+        oracle.orc_bitrev_rows(ptr(lde), log_n + rb, n_polys)
+        leaves = np.ascontiguousarray(lde.T)
+        _, want = oracle_merkle(oracle, leaves, cap_h)
+        got = np.zeros(4 << cap_h, dtype=np.uint64)
+        work = vals.copy()
+        assert oracle.orc_commit_fast(ptr(work), log_n, n_polys, rb, cap_h, 7, ptr(got)) == 0
+        assert np.array_equal(got, np.asarray(want).reshape(-1)), (kind, log_n, n_polys)
+        assert np.array_equal(work, coeffs)                       # the values are left as coefficients
