@@ -50,9 +50,10 @@ def pmc_traffic_bytes(plan_desc, elements):
     mode_id = {"strip": 0, "finalT": 1, "finalRows": 2}
     total = 0.0
     for mode, lr, lc, e32 in re.findall(r"(strip|finalT|finalRows)\(R=2\^(\d+),C=2\^(\d+)(,E=32)?\)", plan_desc):
-        key = (f"void glp_ntt_pass_kernel<{lr}, {mode_id[mode]}, false, {5 if e32 else 4}, {'true' if e32 and mode != 'finalRows' else 'false'}>"
-               f"(GlpNttPassArgs)")
-        ent = t.get(key)
+        # kernel names as rocprofv3 prints them: <LOG_R, MODE, INV, LOG_E, PLAIN, CT_LOG_C>; the instantiation the launcher picks for a plain
+        # natural-order transform (ntt_inst.hip): radix-32 work-items -> PLAIN, and the compile-time tile width where one exists
+        pre = f"void glp_ntt_pass_kernel<{lr}, {mode_id[mode]}, false, {5 if e32 else 4}, {'true' if e32 and mode != 'finalRows' else 'false'}, "
+        ent = t.get(pre + f"{lc}>(GlpNttPassArgs)") or t.get(pre + "-1>(GlpNttPassArgs)")
         if not ent or ent.get("log_c") not in (None, int(lc)):
             return None
         total += (ent["fetch_bytes"] + ent["write_bytes"]) * elements / float(1 << 27)
