@@ -203,6 +203,7 @@ def load_library():
                                                ctypes.POINTER(ctypes.c_size_t), _vp, ctypes.c_size_t, ctypes.c_uint32]),
         "glp_poseidon_permute_host": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t]),
         "glp_gather_u64": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t]),
+        "glp_field_params": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
         "glp_comm_unique_id": (ctypes.c_int, [_vp]),
         "glp_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
         "glp_comm_rank": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
@@ -218,6 +219,16 @@ def load_library():
             fn.argtypes = args
     _lib = lib
     return lib
+
+
+def field_params():
+    """(two-adic generator, log2 of w_64) of the loaded build (glp_field_params)"""
+    lib = load_library()
+    g, e = ctypes.c_uint64(0), ctypes.c_uint32(0)
+    rc = lib.glp_field_params(ctypes.byref(g), ctypes.byref(e))
+    if rc != 0:
+        raise GlpError("glp_field_params: the build's two-adic generator pair is inconsistent")
+    return int(g.value), int(e.value)
 
 
 def _host_verify(fn_name, constants, proof, extra, min_queries, min_pow_bits):

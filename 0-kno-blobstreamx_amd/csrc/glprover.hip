@@ -303,9 +303,20 @@ static int ensure_scratch(glp_ctx* c, size_t bytes) {
 // ---------------------------------------------------------------------------------------
 extern "C" const char* glp_version(void) { return "glprover 0.1 (gfx950)"; }
 
+// the build's two-adic subgroup (gl_field.cuh): generator of order 2^32 and the exponent of w_64 = 2^e
+extern "C" int glp_field_params(uint64_t* two_adic_generator, uint32_t* w64_log2) {
+    if (two_adic_generator) *two_adic_generator = GLP_TWO_ADIC_GENERATOR;
+    if (w64_log2) *w64_log2 = GLP_W64_LOG2;
+    // consistent: order exactly 2^32, and its 2^26-th power is the power of two the shift twiddles assume
+    const u64 g = GLP_TWO_ADIC_GENERATOR;
+    if (g >= GL_P || gl_pow(g, 1ull << 31) != GL_P - 1 || gl_pow(g, 1ull << 26) != gl_pow(2, GLP_W64_LOG2)) return GLP_E_STATE;
+    return GLP_OK;
+}
+
 extern "C" int glp_create(glp_ctx** out, int device_id) {
     if (!out) return GLP_E_INVALID;
     *out = nullptr;
+    if (glp_field_params(nullptr, nullptr) != GLP_OK) return GLP_E_STATE;       // a build with an inconsistent generator pair must not run
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GLP_E_NODEVICE;
     if (device_id < 0 || device_id >= ndev) return GLP_E_INVALID;

@@ -34,9 +34,9 @@ constexpr int glp_bitrev_c(int v, int bits) {
     for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
     return r;
 }
-// exponent e with w_m^i = 2^e (m = 2^k <= 64): w_64 = 2^39 under the generator-7 roots.
+// exponent e with w_m^i = 2^e (m = 2^k <= 64): w_64 = 2^GLP_W64_LOG2 (39 under the default generator-7 roots; gl_field.cuh).
 constexpr int glp_tw_exp(int m, int i, bool inv) {
-    int e = (39 * (64 / m) * i) % 192;
+    int e = (GLP_W64_LOG2 * (64 / m) * i) % 192;
     return inv ? (192 - e) % 192 : e;
 }
 

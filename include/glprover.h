@@ -50,6 +50,11 @@ int glp_create(glp_ctx** out, int device_id);
 void glp_destroy(glp_ctx* ctx);
 const char* glp_last_error(const glp_ctx* ctx);
 const char* glp_version(void);
+/* The two-adic subgroup this BUILD computes in (csrc/gl_field.cuh: GLP_TWO_ADIC_GENERATOR, an element of order 2^32, and GLP_W64_LOG2 with
+ * generator^(2^26) = 2^GLP_W64_LOG2): every root of unity of every transform is a power of that generator.  Default 7^((p-1)/2^32), w_64 = 2^39;
+ * `make -C csrc altgen` builds lib/libglprover_altgen.so on 7277203076849721926, w_64 = 2^3 (recalled as upstream's choice, unverified).
+ * GLP_E_STATE when the compiled pair is inconsistent (glp_create then refuses too).  Either pointer may be NULL. */
+int glp_field_params(uint64_t* two_adic_generator, uint32_t* w64_log2);
 int glp_alloc(glp_ctx* ctx, void** d_ptr, size_t bytes);
 int glp_free(glp_ctx* ctx, void* d_ptr);
 int glp_h2d(glp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);  /* synchronous */

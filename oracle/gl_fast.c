@@ -48,7 +48,8 @@ static uint64_t f_pow(uint64_t a, uint64_t e) {
 void orc_ntt_fast(uint64_t *data, unsigned log_n, uint64_t batch, int inverse) {
     if (log_n == 0) return;
     const uint64_t n = 1ULL << log_n;
-    uint64_t w = f_pow(7, (P - 1) >> log_n);
+    extern uint64_t orc_two_adic_generator(void);        /* gl_oracle.c: the tests set it to the product build's generator */
+    uint64_t w = f_pow(orc_two_adic_generator(), 1ULL << (32 - log_n));
     if (inverse) w = f_pow(w, P - 2);
     /* per-stage twiddles, stage s (half = 2^(s-1)) stored at tw + half - 1 */
     uint64_t *tw = (uint64_t *)malloc(sizeof(uint64_t) * n);

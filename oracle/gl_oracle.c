@@ -45,7 +45,12 @@ uint64_t orc_pow(uint64_t a, uint64_t e) {
 }
 uint64_t orc_inv(uint64_t a) { return orc_pow(a, P - 2); }
 /* primitive 2^k-th root of unity, k <= 32: 7^((p-1)/2^k) */
-uint64_t orc_root(unsigned k) { return orc_pow(7, (P - 1) >> k); }
+/* the primitive 2^k-th root of unity: a power of the two-adic generator (an element of order 2^32).  Default 7^((p-1)/2^32); the product
+ * library fixes its generator at build time (csrc/gl_field.cuh GLP_TWO_ADIC_GENERATOR) and the tests hand the same value to the oracle. */
+static uint64_t TWO_ADIC_GEN = 0;
+void orc_set_two_adic_generator(uint64_t g) { TWO_ADIC_GEN = g % P; }
+uint64_t orc_two_adic_generator(void) { if (!TWO_ADIC_GEN) TWO_ADIC_GEN = orc_pow(7, (P - 1) >> 32); return TWO_ADIC_GEN; }
+uint64_t orc_root(unsigned k) { return orc_pow(orc_two_adic_generator(), 1ULL << (32 - k)); }
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

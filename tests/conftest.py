@@ -29,9 +29,29 @@ def rand_field(rng, shape):
     return ((hi << np.uint64(32)) | lo) % np.uint64(P)
 
 
+def field_params():
+    """(two-adic generator, log2 w_64) of the PRODUCT build under test (GLP_LIB may select the alternative-generator library: csrc `make altgen`)"""
+    return graft.load_package().field_params()
+
+
+def default_generator():
+    return field_params()[0] == pow(7, (P - 1) >> 32, P)
+
+
+def root_of_unity(k):
+    """the primitive 2^k-th root of unity of the build under test"""
+    return pow(field_params()[0], 1 << (32 - k), P)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     lib = graft.load_oracle()
+    lib.orc_set_two_adic_generator.argtypes = [ctypes.c_uint64]
+    lib.orc_two_adic_generator.restype = ctypes.c_uint64
+    try:
+        lib.orc_set_two_adic_generator(field_params()[0])      # the oracle computes in the subgroup generator the product build was compiled with
+    except Exception:  # noqa: BLE001 — product library not built: the oracle keeps its default (generator 7)
+        pass
     lib.orc_add.restype = lib.orc_sub.restype = lib.orc_mul.restype = ctypes.c_uint64
     lib.orc_pow.restype = lib.orc_inv.restype = lib.orc_root.restype = ctypes.c_uint64
     for f in (lib.orc_add, lib.orc_sub, lib.orc_mul, lib.orc_pow):
@@ -97,8 +117,9 @@ def emu():
     # GLP_EMU_ASAN=1 (with LD_PRELOAD=libasan.so, ASAN_OPTIONS=detect_leaks=0): run the kernel bodies
     # under AddressSanitizer + UBSan — the sanitizer leg of the CPU build (GPU ASan is not available)
     asan = os.environ.get("GLP_EMU_ASAN") == "1"
-    subprocess.run(["make", "-s"] + (["asan"] if asan else []), cwd=d, check=True)
-    lib = ctypes.CDLL(os.path.join(d, "libglp_emu_asan.so" if asan else "libglp_emu.so"))
+    alt = os.environ.get("GLP_EMU_ALTGEN") == "1"          # kernel bodies compiled on the alternative two-adic generator (set together with GLP_LIB)
+    subprocess.run(["make", "-s"] + (["asan"] if asan else ["altgen"] if alt else []), cwd=d, check=True)
+    lib = ctypes.CDLL(os.path.join(d, "libglp_emu_asan.so" if asan else "libglp_emu_altgen.so" if alt else "libglp_emu.so"))
     lib.emu_ntt.argtypes = [u64p, u64p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint, ctypes.c_int,
                             ctypes.c_int, ctypes.c_char_p]
     lib.emu_lde_coset_bitrev.argtypes = [u64p, u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64, ctypes.c_char_p]

@@ -332,7 +332,7 @@ extern "C" int emu_plonk_quotient(const u64* consts, const u64* sigmas, const u6
     qa.log_n = log_n; qa.rate_bits = rb; qa.W = W; qa.R = R; qa.n_con = n_con;
     for (int t = 0; t < GLP_PLONK_NCHAL; t++) { qa.beta[t] = beta[t]; qa.gamma[t] = gamma[t]; }
     qa.alpha_pow = apow.data(); qa.pos_consts = pos_consts; qa.w_lo = lo.data(); qa.w_hi = hip; qa.shift = 7;
-    const u64 sn = gl_pow(7, n), wr = gl_root_of_unity(rb);
+    const u64 sn = gl_pow(7, n), wr = gl_root_of_unity(rb);   // 7 here is the coset SHIFT (the multiplicative generator), not the two-adic generator
     for (u32 k = 0; k < (1u << rb); k++) qa.zh_inv[k] = gl_inv(gl_sub(gl_mul(sn, gl_pow(wr, k)), 1));
     qa.n_inv = gl_inv(n % GL_P); qa.inv_xm1 = inv.data(); qa.out = out;
     if (flags & GLP_CIRCUIT_POSEIDON_GATE) {

@@ -53,6 +53,10 @@ CASES = [
 ]
 
 
+if os.environ.get("GLP_EMU_CASE_STRIDE"):                     # the alternative-generator child run takes every k-th case
+    CASES = CASES[::int(os.environ["GLP_EMU_CASE_STRIDE"])]
+
+
 @pytest.mark.parametrize("log_n,batch,inv,rev,plan,in_place", CASES)
 def test_emulated_ntt_vs_oracle(emu, oracle, log_n, batch, inv, rev, plan, in_place):
     rng = np.random.default_rng(1000 + log_n * 7 + batch)
@@ -106,6 +110,8 @@ def test_emulated_coset_lde_bitrev_vs_oracle(emu, oracle, log_n, rb, batch, plan
 
 def test_emulated_coset_lde_bitrev_vs_golden(emu):
     """the by-cosets LDE under emulation against the committed big-int vectors (no oracle in the loop)"""
+    if os.environ.get("GLP_EMU_ALTGEN") == "1":
+        pytest.skip("the golden vectors are generator-7 DFTs")
     with open(os.path.join(G, "lde_bitrev.json")) as f:
         cases = json.load(f)["cases"]
     for c in cases:
@@ -130,3 +136,22 @@ def test_emulated_ntt_strided_batch(emu, oracle):
     oracle.orc_ntt(ptr(ref), log_n, batch, 0)
     assert np.array_equal(dst[:, :n], ref)
     assert np.all(dst[:, n:] == 0xBEEF)
+
+
+def test_emulated_kernels_under_the_alternative_two_adic_generator():
+    """the two-adic generator is a BUILD parameter (csrc/gl_field.cuh): the kernel bodies compiled on 7277203076849721926 (w_64 = 2^3: other
+    shift twiddles in every butterfly, other tables) against the oracle switched to the same generator — every third NTT case and the coset
+    LDE cases, in a child process (the emulation library and the product library it reads the generator from are selected by environment)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    alt = os.path.join(os.path.dirname(here), "0-kno-blobstreamx_amd", "lib", "libglprover_altgen.so")
+    if os.environ.get("GLP_EMU_ALTGEN") == "1":
+        pytest.skip("this IS the alternative-generator run")
+    if not os.path.exists(alt):
+        pytest.skip("lib/libglprover_altgen.so not built (__graft_entry__.build() makes it)")
+    env = dict(os.environ, GLP_LIB=alt, GLP_EMU_ALTGEN="1", GLP_EMU_CASE_STRIDE="3")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k", "emulated_ntt or lde"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=os.path.dirname(here))
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "passed" in r.stdout.strip().splitlines()[-1]
