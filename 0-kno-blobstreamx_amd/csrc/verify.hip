@@ -22,6 +22,7 @@
 #include "hash_state.h"
 #include "challenger.h"
 #include "plonk_gates.h"
+#include "nnf25519.h"
 
 namespace {
 const u64 FRI_TAG = 0x32304952464C4747ull;
@@ -628,6 +629,8 @@ extern "C" int glp_poseidon_permute_host(const uint64_t* h_rc, const uint64_t* h
 //   7 SHA_E T1 e_new e f g h d w K    8 SHA_A a_new a b c T1    9 SHA_W w_new w16 w15 w7 w2    10 ADD32 s x y      (the SHA rows of plonk_gates.h;
 //   11 BITS w x shift bits   w = (x >> shift) mod 2^bits     12 POSEIDON_SWAP o0..o11 i0..i11 s   the Poseidon row with its swap bit
 //   13 EXTMULADD w0 w1 x0 x1 y0 y1 z0 z1   w = x * y + z in the quadratic extension (the extension-arithmetic row)
+//   14 NNF_MUL first a0..a10 b0..b10   variables first..first+43 = remainder, quotient and column carries of a product in the NON-NATIVE field
+//      F_q, q = 2^255 - 19, on 24-bit limbs (nnf25519.h): witness values only, the circuit constrains them with arithmetic gates and range checks
 //     an input that is not a 32-bit word -> GLP_E_REJECT with *first_bad = (size_t)-1: no witness satisfies the row)
 // eq_pairs: 2*n_eq variable indices that must hold equal values (the circuit's copy constraints between DIFFERENT variables): the first
 // violated pair is reported through *first_bad and the call returns GLP_E_REJECT — the witness does not satisfy the circuit (e.g. the
@@ -764,6 +767,19 @@ static int witness_run(const Hasher& h, const u64* prog, size_t pc, size_t end, 
                 if (!wr(a[0]) || !wr(a[1])) return GLP_E_INVALID;
                 values[a[0]] = w.a; values[a[1]] = w.b;
                 pc += 9;
+                break;
+            }
+            case 14: {  // NNF_MUL  first | a0..a10 | b0..b10:  the 44 hint values of a product in F_q, q = 2^255 - 19 (nnf25519.h): r, k, carries
+                if (pc + 2 + 2 * GLP_NNF_LIMBS > end || a[0] >= n_values || a[0] + GLP_NNF_OUT > n_values) return GLP_E_INVALID;
+                u64 va[GLP_NNF_LIMBS], vb[GLP_NNF_LIMBS], out[GLP_NNF_OUT];
+                for (int i = 0; i < GLP_NNF_LIMBS; i++) {
+                    const u64 ia = a[1 + i], ib = a[1 + GLP_NNF_LIMBS + i];
+                    if (!ok(ia) || !ok(ib) || !rd(ia) || !rd(ib)) return GLP_E_INVALID;
+                    va[i] = values[ia]; vb[i] = values[ib];
+                }
+                if (!glp_nnf::mul_hints(va, vb, out)) return GLP_E_REJECT;         // an operand limb out of range: no witness satisfies the product rows
+                for (int i = 0; i < GLP_NNF_OUT; i++) { if (!wr(a[0] + i)) return GLP_E_INVALID; values[a[0] + i] = out[i]; }
+                pc += 2 + 2 * GLP_NNF_LIMBS;
                 break;
             }
             case 11: {  // BITS  w | x shift bits:  w = (x >> shift) mod 2^bits

@@ -239,6 +239,35 @@ class CircuitBuilder:
         self.prog += (11, v, x, shift, bits)
         return v
 
+    def nnf_mul_hints(self, a, b):
+        """the witness values of a product in the NON-NATIVE field F_q, q = 2^255 - 19, on eleven 24-bit limbs (csrc/nnf25519.h, evaluator op 14):
+        for limb variables a[11], b[11] (integer values A, B = sum limb * 2^(24 i); limbs may be loose, below 2^28) returns the 44 new variables
+        (r[11], k[12], c[21]) with A * B = k * q + r, r canonical, and c the carries of the column identity
+            col_t = sum_{i+j=t} a_i b_j + 19 k_t - 2^15 k_(t-10) - r_t,    col_t + c_(t-1) = c_t * 2^24,
+        negative carries stored mod p.  Computed witnesses only: ed25519_circuit.NNF lays down the constraints (gates + range checks)."""
+        assert len(a) == 11 and len(b) == 11
+        av, bv = [self.values[v] for v in a], [self.values[v] for v in b]
+        if any(v >> 28 for v in av + bv):
+            raise ValueError("a non-native product operand limb is out of range: the witness does not satisfy the circuit")
+        A, B = sum(v << (24 * i) for i, v in enumerate(av)), sum(v << (24 * i) for i, v in enumerate(bv))
+        k, r = divmod(A * B, (1 << 255) - 19)
+        rl = [(r >> (24 * i)) & 0xFFFFFF for i in range(11)]
+        kl = [(k >> (24 * i)) & 0xFFFFFF for i in range(12)]
+        assert k >> (24 * 12) == 0
+        cs, carry = [], 0
+        for t in range(22):
+            col = sum(av[i] * bv[t - i] for i in range(11) if 0 <= t - i < 11) + carry
+            col += (19 * kl[t] if t < 12 else 0) - ((kl[t - 10] << 15) if 0 <= t - 10 < 12 else 0) - (rl[t] if t < 11 else 0)
+            assert col % (1 << 24) == 0
+            carry = col >> 24
+            if t < 21:
+                cs.append(carry)
+        assert carry == 0
+        first = len(self.values)
+        out = [self._new(v) for v in rl + kl + cs]
+        self.prog += (14, first, *a, *b)
+        return out[:11], out[11:23], out[23:]
+
     def ext_mul_add(self, x, y, z):
         """w = x * y + z in F_p[X]/(X^2 - 7) for pairs of variables: ONE chunk of an extension-arithmetic row (8 wires) instead of six
         arithmetic gates.  Needs ext_gate=True."""
