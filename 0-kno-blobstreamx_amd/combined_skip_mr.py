@@ -32,9 +32,13 @@ N_PUBLIC = 30
 
 class CombinedSkipMapReduce:
     def __init__(self, prover, poseidon_consts, skip, batch=8, fan_in=8, num_queries=28, pow_bits=16, map_provers=(), height_varint_bytes=4,
-                 field_lengths=(4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22), max_skip=1 << 20, chain=None):
+                 field_lengths=(4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22), max_skip=1 << 20, chain=None, signatures=None):
         """chain: a HeaderChainMapReduce of the same batch / fan-in / parameters to SHARE (its leaf and node recordings serve every skip length;
-        it is then not freed by free())"""
+        it is then not freed by free()).
+        signatures: a signature_mr.SignatureSetMapReduce (same query / PoW parameters): prove_skip(..., votes=(signatures, vote bytes)) then
+        ALSO proves the target validators' Ed25519 signatures (one leaf per slot, folded to a root) and the outer circuit verifies that root and
+        equates its block hash with the target header hash and its signer digest with the one the power rules were computed from — the
+        statement is then complete, signatures included.  Not freed by free()."""
         if skip % batch or skip < batch:
             raise ValueError("skip must be a whole number of batches")
         self.prover, self.consts = prover, tuple(np.ascontiguousarray(a, dtype=np.uint64) for a in poseidon_consts)
@@ -45,14 +49,18 @@ class CombinedSkipMapReduce:
             height_varint_bytes=height_varint_bytes, field_lengths=field_lengths)
         if (self.chain.leaf_blocks, self.chain.nq, self.chain.pw) != (batch, num_queries, pow_bits):
             raise ValueError("the shared chain object has other parameters")
-        self.outer = {}                  # (chain root key, trusted_index) -> RecursionProgram
+        self.outer = {}                  # (chain root key, trusted_index, ..., signature root key) -> RecursionProgram
         self.record_seconds = {}
+        self.sigs = signatures
+        if signatures is not None and (signatures.nq, signatures.pw) != (num_queries, pow_bits):
+            raise ValueError("the signature MapReduce has other parameters")
 
     # ---- the outer circuit ------------------------------------------------------------------------------------------------------------
-    def _outer(self, chain_root, chain_key, chain_is_node, sample):
+    def _outer(self, chain_root, chain_key, chain_is_node, sample, sig_root=None, sig_key=None):
         vc = importlib.import_module(__package__ + ".verifier_circuit")
         tf, trusted, vf, target, signed, idx, h0 = sample
-        k = (bytes(np.ascontiguousarray(chain_key, dtype=np.uint64)), tuple(idx), len(trusted[0]), len(target[0]))
+        k = (bytes(np.ascontiguousarray(chain_key, dtype=np.uint64)), tuple(idx), len(trusted[0]), len(target[0]),
+             None if sig_key is None else bytes(np.ascontiguousarray(sig_key, dtype=np.uint64)))
         if k in self.outer:
             return self.outer[k]
         t0 = time.perf_counter()
@@ -60,7 +68,7 @@ class CombinedSkipMapReduce:
 
         def combine(b, outs):
             g = Sha256Rows(b)
-            b.auto_tag_list, b._auto_pos = 1, 0                       # the skip statement's free inputs come from word list 1 (list 0 = the proof)
+            b.auto_tag_list, b._auto_pos = (1 if sig_root is None else 2), 0     # the skip statement's free inputs: the word list after the proof(s)
             ht, hv, sd, blocks = skip_statement(b, g, tf, trusted, vf, target, signed, idx, heights=(h0, h0 + skip), max_skip=self.max_skip)
             b.auto_tag_list = None
             pub = outs[0]["public"]                                   # the chain root's statement: start (8), end (8), R (8), first height
@@ -68,10 +76,19 @@ class CombinedSkipMapReduce:
                 b.assert_equal(x, y)                                  # the chain walks from THE trusted header to THE target header
             b.assert_equal(b.arith(0, 1, 1, blocks[0], blocks[0], blocks[0]), pub[24])            # first chain height = trusted block + 1
             b.assert_equal(b.arith(0, 1, skip, blocks[0], blocks[0], blocks[0]), blocks[1])       # target block = trusted block + skip
+            if sig_root is not None:
+                ps = outs[1]["public"]                                # the signature set's root: block hash (8), signer digest (4)
+                for x, y in zip(hv + sd, ps[:12]):
+                    b.assert_equal(x, y)                              # the votes name THE target header, the flags are the verified slots
             return ht + hv + sd + blocks + pub[16:24]
-        rp = vc.RecursionProgram(self.prover, [chain_root], chain_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80,
+        chain_spec = dict(leaf_key=chain_key, n_public=HeaderChainMapReduce.N_PUBLIC, child_is_recursion=chain_is_node)
+        proofs, specs = [chain_root], [chain_spec]
+        if sig_root is not None:
+            proofs.append(sig_root)
+            specs.append(dict(leaf_key=sig_key, n_public=self.sigs.N_PUBLIC, child_is_recursion=True))
+        rp = vc.RecursionProgram(self.prover, proofs, chain_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80,
                                  n_public=HeaderChainMapReduce.N_PUBLIC, cap_height=1, child_is_recursion=chain_is_node, child_sha=True,
-                                 combine=combine, builder_wires=SHA_GATE_WIRES)
+                                 combine=combine, builder_wires=SHA_GATE_WIRES, specs=specs)
         self.record_seconds["outer"] = round(time.perf_counter() - t0, 3)
         self.outer[k] = rp
         return rp
@@ -82,21 +99,34 @@ class CombinedSkipMapReduce:
         if tuple(len(bytes(f)) for f in trusted_fields) != self.chain.field_lengths:
             raise ValueError("the trusted header's field encodings do not have the recorded lengths")
 
-    def _finish(self, root_chain, chain_key, chain_is_node, case, t_chain):
+    def _finish(self, root_chain, chain_key, chain_is_node, case, t_chain, sig_out=None):
         tf, trusted, chain_headers, target, signed, idx, h0 = case
         vf = chain_headers[-1]
-        rp = self._outer(root_chain, chain_key, chain_is_node, (tf, trusted, vf, target, signed, idx, h0))
+        sig_root, sig_key = (sig_out["root_proof"], sig_out["key"]) if sig_out is not None else (None, None)
+        rp = self._outer(root_chain, chain_key, chain_is_node, (tf, trusted, vf, target, signed, idx, h0), sig_root, sig_key)
         t0 = time.perf_counter()
         words = np.array(skip_statement_inputs(tf, trusted, vf, target, signed, heights=(h0, h0 + self.skip)), dtype=np.uint64)
-        proof, public = rp.prove([root_chain, words], self.nq, self.pw)
+        # word lists in the order the outer circuit tagged them: the verified proofs first, the skip statement's witness last
+        proof, public = rp.prove([root_chain] + ([sig_root] if sig_root is not None else []) + [words], self.nq, self.pw)
         t1 = time.perf_counter()
         be = lambda ws: b"".join(struct.pack(">I", v) for v in ws)
         return {"root_proof": proof, "public": public, "key": rp.key(), "outer_seconds": round(t1 - t0, 4), "chain_seconds": round(t_chain, 4),
+                "signatures_in_circuit": sig_root is not None,
                 "trusted_hash": be(public[:8]), "target_hash": be(public[8:16]), "signer_digest": public[16:20], "trusted_block": public[20],
                 "target_block": public[21], "commitment": be(public[22:30]), "outer_rows": rp.stats["rows"]}
 
     # ---- proving ----------------------------------------------------------------------------------------------------------------------
-    def prove_skip(self, trusted_fields, trusted, chain_headers, target, signed, trusted_index, trusted_height):
+    def _prove_votes(self, target, signed, votes, chain_headers, distributed=None):
+        if votes is None:
+            return None
+        if self.sigs is None:
+            raise ValueError("this object was made without a signature MapReduce")
+        sigs, msgs = votes
+        if distributed is None:
+            return self.sigs.prove_set(target[0], sigs, msgs, signed)
+        return self.sigs.prove_set_distributed(target[0], sigs, msgs, signed, **distributed)
+
+    def prove_skip(self, trusted_fields, trusted, chain_headers, target, signed, trusted_index, trusted_height, votes=None):
         """trusted_fields: the trusted header's 14 field encodings (its field 2 = height, field 8 = BytesValue(hash of `trusted`));
         chain_headers: the `skip` headers after it, the last one being the target (its field 7 = BytesValue(hash of `target`)), each linked to its
         predecessor through field 4 and carrying its height in field 2; trusted / target = (pubkeys, voting_powers); signed = the target
@@ -106,13 +136,20 @@ class CombinedSkipMapReduce:
         t0 = time.perf_counter()
         out = self.chain.prove_chain(start, trusted_height + 1, chain_headers)
         t_chain = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sig_out = self._prove_votes(target, signed, votes, chain_headers)
+        t_sig = time.perf_counter() - t0
         res = self._finish(out["root_proof"], out["key"], out["leaves"] > 1, (trusted_fields, trusted, chain_headers, target, signed, trusted_index,
-                                                                               trusted_height), t_chain)
+                                                                               trusted_height), t_chain, sig_out)
         res.update(leaves=out["leaves"], map_seconds=out["map_seconds"], reduce_seconds=out["reduce_seconds"], levels=out["levels"],
                    record_seconds=dict(self.chain.record_seconds, **self.record_seconds))
+        if sig_out is not None:
+            res.update(signature_seconds=round(t_sig, 4), signature_slots=sig_out["slots"], signature_map_seconds=sig_out["map_seconds"],
+                       signature_levels=sig_out["levels"], signature_record_seconds=sig_out["record_seconds"])
         return res
 
-    def prove_skip_distributed(self, trusted_fields, trusted, chain_headers, target, signed, trusted_index, trusted_height, device=None, comm=None):
+    def prove_skip_distributed(self, trusted_fields, trusted, chain_headers, target, signed, trusted_index, trusted_height, device=None, comm=None,
+                               votes=None):
         """prove_skip with the chain spread over the ranks (HeaderChainMapReduce.prove_chain_distributed); the outer circuit is proved on rank 0.
         Every rank passes the whole case.  Returns the prove_skip dict on rank 0, {"root_proof": None, ...} elsewhere."""
         self._check_shapes(trusted_fields, chain_headers, trusted_height)
@@ -120,23 +157,57 @@ class CombinedSkipMapReduce:
         t0 = time.perf_counter()
         out = self.chain.prove_chain_distributed(start, trusted_height + 1, chain_headers, device=device, comm=comm)
         t_chain = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sig_out = self._prove_votes(target, signed, votes, chain_headers, distributed=dict(device=device, comm=comm))       # every rank takes part
+        t_sig = time.perf_counter() - t0
         if out["root_proof"] is None:
-            return {"root_proof": None, "map_seconds": out["map_seconds"], "chain_seconds": round(t_chain, 4), "leaves": out["leaves"], "ranks": out["ranks"]}
+            return {"root_proof": None, "map_seconds": out["map_seconds"], "chain_seconds": round(t_chain, 4), "leaves": out["leaves"], "ranks": out["ranks"],
+                    "signature_seconds": round(t_sig, 4), "signature_map_seconds": sig_out["map_seconds"] if sig_out else None}
         res = self._finish(out["root_proof"], out["key"], out["leaves"] > 1, (trusted_fields, trusted, chain_headers, target, signed, trusted_index,
-                                                                               trusted_height), t_chain)
+                                                                               trusted_height), t_chain, sig_out)
         res.update(leaves=out["leaves"], ranks=out["ranks"], map_seconds=out["map_seconds"], levels=out["levels"],
                    record_seconds=dict(self.chain.record_seconds, **self.record_seconds))
+        if sig_out is not None:
+            res.update(signature_seconds=round(t_sig, 4), signature_slots=sig_out["slots"], signature_map_seconds=sig_out["map_seconds"],
+                       signature_levels=sig_out["levels"], signature_record_seconds=sig_out["record_seconds"])
         return res
 
     # ---- the consumer -----------------------------------------------------------------------------------------------------------------
-    def synthetic_case(self, n_trusted, n_target, trusted_index, trusted_height=None, power_groups=6, seed=0):
+    def synthetic_votes(self, case, seeds):
+        """the target validators' vote bytes and Ed25519 signatures for a case made with real_keys=True: (signatures, vote bytes) for prove_skip's
+        `votes` — every flagged validator signs the vote naming the target header's hash"""
+        from .ed25519_circuit import keypair_and_sign
+        _, _, chain, (vk, _), signed, _, _ = case
+        target_hash = HeaderChainMapReduce.header_hash(chain[-1])
+        msgs = [self.sigs.vote_bytes(target_hash, i) for i in range(len(vk))]
+        sigs = []
+        for i, (key, sg) in enumerate(zip(vk, signed)):
+            if not sg:
+                sigs.append(None)
+                continue
+            pub, sig = keypair_and_sign(seeds[i], msgs[i])
+            assert pub == key
+            sigs.append(sig)
+        return sigs, msgs
+
+    def synthetic_case(self, n_trusted, n_target, trusted_index, trusted_height=None, power_groups=6, seed=0, real_keys=False):
         """a well-formed case of this object's shape (used by expected_key, tests and the bench): random keys, powers with `power_groups` varint
         groups, every target validator flagged, headers with random opaque fields and real links, heights, validator-set hashes.
-        Returns the prove_skip argument tuple."""
+        real_keys: the validators' keys are real Ed25519 public keys (derived from per-validator seeds, returned as an eighth element) so that
+        synthetic_votes can sign for them.  Returns the prove_skip argument tuple (+ the target validators' seeds with real_keys)."""
         bs = importlib.import_module(__package__ + ".blobstream")
         rng = np.random.default_rng(seed)
         h0 = (1 << (7 * (self.chain.n_groups - 1))) + 17 if trusted_height is None else int(trusted_height)
-        key = lambda: rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+        seeds_by_key = {}
+
+        def key():
+            if not real_keys:
+                return rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+            from .ed25519_circuit import keypair_and_sign
+            sd = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+            pub, _ = keypair_and_sign(sd, b"")
+            seeds_by_key[pub] = sd
+            return pub
         power = lambda: int(rng.integers(1 << (7 * (power_groups - 1)), 1 << (7 * power_groups - 1)))
         tk, tp = [key() for _ in range(n_trusted)], [power() for _ in range(n_trusted)]
         vk = [tk[t] if t is not None else key() for t in trusted_index]
@@ -156,12 +227,16 @@ class CombinedSkipMapReduce:
                 f[7] = b"\x0a\x20" + bs.validator_set_hash(self.prover, vk, vp)
             chain.append(f)
             prev = HeaderChainMapReduce.header_hash(f)
-        return tf, (tk, tp), chain, (vk, vp), [True] * n_target, list(trusted_index), h0
+        case = (tf, (tk, tp), chain, (vk, vp), [True] * n_target, list(trusted_index), h0)
+        return case + ([seeds_by_key[k] for k in vk],) if real_keys else case
 
     def expected_key(self, n_trusted, n_target, trusted_index, power_groups=6):
         """the VERIFIER's own setup: the outer circuit's verifying key for this shape, from a synthetic case proved on this object (see
         DataCommitmentMapReduce.expected_key: a key must never be taken from the prover)"""
-        return self.prove_skip(*self.synthetic_case(n_trusted, n_target, trusted_index, power_groups=power_groups))["key"]
+        if self.sigs is None:
+            return self.prove_skip(*self.synthetic_case(n_trusted, n_target, trusted_index, power_groups=power_groups))["key"]
+        *case, seeds = self.synthetic_case(n_trusted, n_target, trusted_index, power_groups=power_groups, real_keys=True)
+        return self.prove_skip(*case, votes=self.synthetic_votes(case, seeds))["key"]
 
     def verify(self, root_proof, key, trusted_hash, target_hash, signer_digest, trusted_block, target_block, commitment):
         public = list(struct.unpack(">8I", bytes(trusted_hash))) + list(struct.unpack(">8I", bytes(target_hash))) + [int(v) for v in signer_digest] + \

@@ -68,12 +68,17 @@ class DataCommitmentMapReduce:
     N_PUBLIC = 12                       # public inputs of every proof of the tree: R (8 words) then D (4 words)
 
     def _combine_for(self, span):
-        """the node's statement-combining hook; span = how many leaf units (blocks) each child covers at this level"""
+        """the node's statement-combining hook; span = how many leaf units (blocks) each child covers at this level (span == leaf_blocks:
+        the children are leaf proofs)"""
         return _combine
 
     def _child_has_poseidon_rows(self, level):
         """the circuit flags of the proofs a level-`level` node verifies: here leaves hash their tuples with Poseidon rows, nodes always have them"""
         return True
+
+    def _child_n_public(self, level):
+        """public inputs of the proofs a level-`level` node verifies (the same at every level here)"""
+        return self.N_PUBLIC
 
     def __init__(self, prover, poseidon_consts, leaf_blocks=64, fan_in=8, num_queries=28, pow_bits=16, map_provers=()):
         """map_provers: further Provers on the same GPU (their Poseidon constants set): the Map step then proves leaves on all of them at once,
@@ -144,7 +149,7 @@ class DataCommitmentMapReduce:
         if k not in self.nodes:
             t0 = time.perf_counter()
             self.nodes[k] = vc.RecursionProgram(self.prover, proofs, child_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80,
-                                                n_public=self.N_PUBLIC, cap_height=1, child_is_recursion=self._child_has_poseidon_rows(level), child_sha=True,
+                                                n_public=self._child_n_public(level), cap_height=1, child_is_recursion=self._child_has_poseidon_rows(level), child_sha=True,
                                                 combine=self._combine_for(span), builder_wires=SHA_GATE_WIRES)
             self.record_seconds[f"node_level{level}_fan{len(proofs)}"] = round(time.perf_counter() - t0, 3)
         return self.nodes[k]

@@ -503,35 +503,83 @@ def _limbs_from_byte_bits(g, byte_bits, n_limbs):
     return [g.pack(flat[LB * i: LB * i + LB]) for i in range(n_limbs) if flat[LB * i: LB * i + LB]]
 
 
-def witness_inputs(pub32, sig64, msg):
+_DUMMY = {}
+
+
+def dummy_signature(msg_len):
+    """a fixed valid (public key, signature, message) triple for messages of this length: what a slot whose `signed` flag is 0 verifies instead of
+    its validator's signature (the circuit cannot skip constraints, it selects their inputs)"""
+    if msg_len not in _DUMMY:
+        m = bytes(msg_len)
+        pub, sig = keypair_and_sign(hashlib.sha256(b"glprover unsigned slot").digest(), m)
+        _DUMMY[msg_len] = (pub, sig, m)
+    return _DUMMY[msg_len]
+
+
+def witness_inputs(pub32, sig64, msg, flag=None):
     """the input vector of a program recorded from verify_statement for a message of this length, in the order the statement creates its free
-    variables: A bytes, R bytes, S bytes, message bytes, then the limbs of x_A, x_R, of the quotient t and of k = SHA-512(R || A || M) mod L.
-    ValueError when A or R does not decode (no witness exists)."""
-    pub32, sig64, msg = bytes(pub32), bytes(sig64), bytes(msg)
+    variables: [with a flag: the flag, the validator's key bytes, the message bytes, then for the VERIFIED triple — the validator's own when the
+    flag is 1, dummy_signature's when it is 0 —] A bytes, R bytes, S bytes, message bytes [without a flag only], then the limbs of x_A, x_R, of
+    the quotient t and of k = SHA-512(R || A || M) mod L.  ValueError when A or R does not decode (no witness exists)."""
+    pub32, msg = bytes(pub32), bytes(msg)
+    head = []
+    if flag is not None:
+        head = [1 if flag else 0] + list(pub32) + list(msg)
+        if not flag:
+            pub32, sig64, msg = dummy_signature(len(msg))
+    sig64 = bytes(sig64)
+    if len(sig64) != 64:
+        raise ValueError("a signature is 64 bytes")
     ya, yr = int.from_bytes(pub32, "little"), int.from_bytes(sig64[:32], "little")
     xa, xr = recover_x(ya & ((1 << 255) - 1), ya >> 255), recover_x(yr & ((1 << 255) - 1), yr >> 255)
     if xa is None or xr is None:
         raise ValueError("the public key or R does not decode to a curve point")
     h = int.from_bytes(hashlib.sha512(sig64[:32] + pub32 + msg).digest(), "little")
     t, k = divmod(h, ELL)
-    return list(pub32) + list(sig64[:32]) + list(sig64[32:]) + list(msg) + limbs_of(xa) + limbs_of(xr) + limbs_of(t) + limbs_of(k)
+    body = (list(pub32) if flag is None else []) + list(sig64[:32]) + list(sig64[32:]) + (list(msg) if flag is None else [])
+    return head + body + limbs_of(xa) + limbs_of(xr) + limbs_of(t) + limbs_of(k)
 
 
-def verify_statement(b, pub32, sig64, msg):
+def verify_statement(b, pub32, sig64, msg, flag=None):
     """Lay down, on builder b (144 wires: the range checks use ADD rows), the verification of ONE Ed25519 signature (RFC 8032 §5.1.7, equation
-    [S]B = R + [k]A).  Free inputs in witness_inputs' order.  Returns {"key_words": 8 big-endian 32-bit word variables of the public key,
-    "msg_bytes": the message byte variables, "stats": {...}}.  ValueError when the signature does not verify (some constraint fails on its
-    witness)."""
-    pub32, sig64, msg = bytes(pub32), bytes(sig64), bytes(msg)
-    vals = witness_inputs(pub32, sig64, msg)
+    [S]B = R + [k]A).  Free inputs in witness_inputs' order.  flag (None, or the slot's `signed` value): with a flag the statement is
+    "flag = 1  =>  sig64 is the key's signature of msg" — the key and message that enter the verification are SELECTED by the flag between the
+    slot's own and dummy_signature's (a slot that did not sign verifies the fixed dummy triple), so one circuit serves signers and non-signers.
+    Returns {"key_words": 8 big-endian 32-bit word variables of the slot's public key, "msg_bytes": the message byte variables,
+    "flag": the flag variable or None, "stats": {...}}.  ValueError when the signature does not verify (some constraint fails on its witness)."""
+    pub32, msg = bytes(pub32), bytes(msg)
+    vals = witness_inputs(pub32, sig64, msg, flag)
     it = iter(vals)
     f = NNF(b)
     g = Sha512Gadget(b)
     ed = Edwards(f)
-    A_bytes = [_byte_input(b, g, next(it)) for _ in range(32)]
+
+    def decomposed(v):
+        bits = [b.bit(v, i) for i in range(8)]
+        for bit in bits:
+            b.assert_bool(bit)
+        b.assert_equal(g.pack(bits), v)
+        return v, bits
+    flag_var = None
+    if flag is None:
+        A_bytes = [_byte_input(b, g, next(it)) for _ in range(32)]
+        own_key = A_bytes
+    else:
+        flag_var = b.var(next(it))
+        b.assert_bool(flag_var)
+        own_key = [_byte_input(b, g, next(it)) for _ in range(32)]
+        own_msg = [_byte_input(b, g, next(it)) for _ in range(len(msg))]
+        d_pub, _, d_msg = dummy_signature(len(msg))
+        # flag ? own : dummy  =  dummy + flag * (own - dummy), byte by byte; the selected byte is decomposed again (it feeds the hash)
+        pick = lambda own, dv: decomposed(b.arith(1, 0, dv, flag_var, b.arith(1, 0, P - dv, own, f.one, own), flag_var))
+        A_bytes = [pick(v, dv) for (v, _), dv in zip(own_key, d_pub)]
     R_bytes = [_byte_input(b, g, next(it)) for _ in range(32)]
     S_bytes = [_byte_input(b, g, next(it)) for _ in range(32)]
-    M_bytes = [_byte_input(b, g, next(it)) for _ in range(len(msg))]
+    if flag is None:
+        M_bytes = [_byte_input(b, g, next(it)) for _ in range(len(msg))]
+        own_msg = M_bytes
+    else:
+        M_bytes = [pick(v, dv) for (v, _), dv in zip(own_msg, d_msg)]
     x_a, x_r = f.witness(sum(next(it) << (LB * i) for i in range(NL))), f.witness(sum(next(it) << (LB * i) for i in range(NL)))
     t_q = f.witness(sum(next(it) << (LB * i) for i in range(NL)))
     k_s = f.witness(sum(next(it) << (LB * i) for i in range(NL)))
@@ -587,10 +635,10 @@ def verify_statement(b, pub32, sig64, msg):
     f.assert_equal(f.mul(Q1[1], Q3[2]), f.mul(Q3[1], Q1[2]))
     key_words = []
     for wd in range(8):                                                          # big-endian 32-bit words of the key bytes (the signer digest's form)
-        bs = [A_bytes[4 * wd + j][0] for j in range(4)]
+        bs = [own_key[4 * wd + j][0] for j in range(4)]
         hi = b.arith(1 << 24, 1, 0, bs[0], f.one, b.arith(1 << 16, 0, 0, bs[1], f.one, bs[1]))
         key_words.append(b.arith(1 << 8, 1, 0, bs[2], f.one, b.arith(1, 1, 0, hi, f.one, bs[3])))
-    return {"key_words": key_words, "msg_bytes": [v for v, _ in M_bytes], "stats": {"field_products": f.n_mul}}
+    return {"key_words": key_words, "msg_bytes": [v for v, _ in own_msg], "flag": flag_var, "stats": {"field_products": f.n_mul}}
 
 
 def ed25519_circuit(prover, pub32, sig64, msg):

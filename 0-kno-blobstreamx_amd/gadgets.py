@@ -446,29 +446,55 @@ def _height_field(b, g, height):
     return hv, [b.constant(0x08)] + [b.arith(0, 1, 0x80, v, v, v) for v in gv[:-1]] + [gv[-1]]
 
 
+def signer_leaf(b, key_words, flag):
+    """the 4-word leaf of the signer digest tree for one validator slot: Poseidon hash_no_pad over the 8 big-endian words of its key and its flag"""
+    return b.hash_no_pad(list(key_words) + [flag])
+
+
+def signer_tree(b, leaves):
+    """binary Poseidon two_to_one tree over a power-of-two list of 4-word leaves"""
+    level = list(leaves)
+    while len(level) > 1:
+        level = [b.two_to_one(level[k], level[k + 1]) for k in range(0, len(level), 2)]
+    return level[0]
+
+
 def _signer_digest(b, g, keys, flags):
-    """Poseidon hash_no_pad over (the 8 big-endian words of each validator's key, its signed flag): 9 elements per validator.  Exposed as public
-    input it BINDS the proof to who was flagged — the hook for the hybrid check (blobstream.verify_signers): the Ed25519 signatures of exactly
-    these validators are verified natively, outside the circuit."""
-    elems = []
-    for kb, f in zip(keys, flags):
-        elems += [g.word_from_bytes(kb[k:k + 4]) for k in range(0, 32, 4)] + [f]
-    return b.hash_no_pad(elems)
+    """The SIGNER DIGEST: a binary Poseidon tree over one leaf per validator slot — hash_no_pad(the 8 big-endian words of the key, the signed
+    flag) — padded to a power of two with the leaf of an all-zero key and flag 0.  Exposed as public input it BINDS the proof to who was flagged.
+    A TREE (round 3; it was one long sponge) so that the same digest can be assembled by a MapReduce over the slots: signature_mr.py proves, per
+    slot, "flag = 1 => the slot's key signed the vote" and folds the slots' leaves into exactly this root, which the CombinedSkip outer circuit
+    equates with the one computed here — the Ed25519 half of the statement, in-circuit.  (blobstream.verify_signers, the native check of the
+    flagged signatures against this digest, remains for proofs without that half.)"""
+    leaves = [signer_leaf(b, [g.word_from_bytes(kb[k:k + 4]) for k in range(0, 32, 4)], f) for kb, f in zip(keys, flags)]
+    n = 1 << max(0, (len(leaves) - 1).bit_length())
+    if n > len(leaves):
+        zero = b.constant(0)
+        pad = signer_leaf(b, [zero] * 8, zero)
+        leaves += [pad] * (n - len(leaves))
+    return signer_tree(b, leaves)
 
 
-def signer_digest_host(poseidon_consts, pubkeys, signed):
-    """the same digest on the host (what a consumer recomputes from the keys and flags it was given)"""
+def signer_digest_host(poseidon_consts, pubkeys, signed, pad_to=None):
+    """the same digest on the host (what a consumer recomputes from the keys and flags it was given); pad_to: number of slots (a power of two
+    >= len(pubkeys), default the next power of two)"""
     from . import poseidon_permute_host
     import numpy as np
-    elems = []
-    for key, sg in zip(pubkeys, signed):
-        elems += list(struct.unpack(">8I", bytes(key))) + [1 if sg else 0]
-    state = np.zeros(12, dtype=np.uint64)
-    for off in range(0, len(elems), 8):
-        chunk = elems[off:off + 8]
-        state[:len(chunk)] = chunk
-        state = poseidon_permute_host(poseidon_consts, state)[0]
-    return [int(v) for v in state[:4]]
+
+    def hash_no_pad(elems):
+        state = np.zeros(12, dtype=np.uint64)
+        for off in range(0, len(elems), 8):
+            chunk = elems[off:off + 8]
+            state[:len(chunk)] = chunk
+            state = poseidon_permute_host(poseidon_consts, state)[0]
+        return [int(v) for v in state[:4]]
+    level = [hash_no_pad(list(struct.unpack(">8I", bytes(key))) + [1 if sg else 0]) for key, sg in zip(pubkeys, signed)]
+    n = pad_to or (1 << max(0, (len(level) - 1).bit_length()))
+    level += [hash_no_pad([0] * 9)] * (n - len(level))
+    while len(level) > 1:
+        st = np.array([level[2 * k] + level[2 * k + 1] + [0, 0, 0, 0] for k in range(len(level) // 2)], dtype=np.uint64)
+        level = [[int(v) for v in row[:4]] for row in poseidon_permute_host(poseidon_consts, st)]
+    return level[0]
 
 
 def step_statement(b, g, trusted_header_fields, target_header_fields, validators, signed, trusted_height=None):

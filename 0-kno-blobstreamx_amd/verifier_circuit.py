@@ -657,22 +657,29 @@ class RecursionProgram:
     (ValueError): some copy constraint of the verifier circuit fails on its witness."""
 
     def __init__(self, prover, sample_proofs, leaf_key, num_queries, pow_bits, n_wires, poseidon_values, n_routed=None, n_public=0, cap_height=4,
-                 child_is_recursion=False, child_sha=False, combine=None, builder_wires=136, ext_gate=False, child_ext=False):
+                 child_is_recursion=False, child_sha=False, combine=None, builder_wires=136, ext_gate=False, child_ext=False, specs=None):
         """combine(b, outs) -> [public input variables]: what the node states about its children, laid down after their verification
         (outs[k] = {"public": child k's public-input variables, "digest": its 4 digest variables}).  Default: every child's public inputs and
         digest, then the Poseidon root of the digests.  builder_wires: wire count of THIS circuit (144 when combine uses SHA rows).
         ext_gate: lay THIS circuit down with extension-arithmetic rows (its proofs then carry flag 4: whoever verifies them in-circuit passes
-        child_ext=True)."""
+        child_ext=True).
+        specs: one dict per proof overriding (leaf_key, n_wires, n_routed, n_public, cap_height, child_is_recursion, child_sha, child_ext) — the
+        children may then be proofs of DIFFERENT circuits (e.g. a header-chain root and a signature-set root under one outer statement); with
+        specs any number of proofs is accepted."""
         from .recursion import CircuitBuilder
         n = len(sample_proofs)
-        assert n >= 1 and n & (n - 1) == 0, "a power-of-two number of proofs"
+        assert n >= 1 and (specs is not None or n & (n - 1) == 0), "a power-of-two number of proofs"
         self.prover, self.consts = prover, poseidon_values
         b = CircuitBuilder(prover, n_wires=builder_wires, ext_gate=ext_gate)
         outs = []
         for k, proof in enumerate(sample_proofs):
             b.begin_segment()            # one proof's verifier depends on constants and on itself: the witness evaluator runs them in parallel
-            outs.append(verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_routed, n_public, cap_height,
-                                          poseidon_values if child_is_recursion else None, proof_id=k, sha=child_sha, ext=child_ext))
+            sp = dict(leaf_key=leaf_key, n_wires=n_wires, n_routed=n_routed, n_public=n_public, cap_height=cap_height,
+                      child_is_recursion=child_is_recursion, child_sha=child_sha, child_ext=child_ext)
+            if specs is not None:
+                sp.update(specs[k])
+            outs.append(verify_in_circuit(b, proof, sp["leaf_key"], num_queries, pow_bits, sp["n_wires"], sp["n_routed"], sp["n_public"], sp["cap_height"],
+                                          poseidon_values if sp["child_is_recursion"] else None, proof_id=k, sha=sp["child_sha"], ext=sp["child_ext"]))
             b.end_segment()
         if combine is None:
             level = []

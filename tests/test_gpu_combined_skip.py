@@ -132,3 +132,62 @@ def test_combined_skip_128_and_1024_at_baseline_sizes(prover, oracle, pkg):
     chain.free()
     for p in extra:
         p.close()
+
+
+@pytest.mark.gpu
+def test_combined_skip_with_the_signatures_in_circuit(prover, oracle, pkg):
+    """the COMPLETE statement on a small tree: header chain (4 leaves of 2 headers) + the skip rules + the target validators' Ed25519 signatures —
+    one leaf per slot (5 validators padded to 8 slots, one of them unsigned), folded by nodes that require a common block hash and assemble the
+    signer digest, and an outer circuit that verifies BOTH roots and equates the signatures' block hash and digest with the skip statement's.
+    A forged signature, a vote for another block, or a flag without a signature cannot be proved."""
+    cs, dm, gd, bs = _mods()
+    sm = importlib.import_module(graft.PKG_NAME + ".signature_mr")
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    idx = [0, 1, 2, None, None]
+    sigs = sm.SignatureSetMapReduce(prover, consts, msg_len=48, hash_offset=8, fan_in=2, num_queries=6, pow_bits=4)
+    mr = cs.CombinedSkipMapReduce(prover, consts, skip=8, batch=2, fan_in=2, num_queries=6, pow_bits=4, max_skip=100, signatures=sigs)
+    *case, seeds = mr.synthetic_case(4, 5, idx, trusted_height=2_500_000, power_groups=3, seed=11, real_keys=True)
+    case[4] = [True, True, True, True, False]                                  # the last validator did not sign
+    votes = mr.synthetic_votes(case, seeds)
+    assert votes[0][4] is None
+    out = mr.prove_skip(*case, votes=votes)
+    want = _expected(dm, gd, consts, tuple(case), 8)
+    assert out["signatures_in_circuit"] and out["signature_slots"] == 8 and {k: out[k] for k in want} == want
+    assert want["signer_digest"] == gd.signer_digest_host(consts, case[3][0], case[4], pad_to=8)
+    assert mr.verify(out["root_proof"], out["key"], **want), prover.last_reject
+    pref.verify_plonk(out["root_proof"], oracle, pos_consts=consts, public=out["public"])
+    assert not mr.verify(out["root_proof"], out["key"], **dict(want, signer_digest=gd.signer_digest_host(consts, case[3][0], [True] * 5, pad_to=8)))
+    # the signature root alone: what it states, and that it is bound to it
+    so = sigs.prove_set(case[3][0], votes[0], votes[1], case[4])
+    assert so["block_hash"] == want["target_hash"] and so["signer_digest"] == want["signer_digest"]
+    assert sigs.verify_set(so["root_proof"], so["key"], so["block_hash"], so["signer_digest"])
+    assert not sigs.verify_set(so["root_proof"], so["key"], bytes(32), so["signer_digest"])
+    # a forged signature of a flagged validator: no witness
+    bad = list(votes[0])
+    forged = bytearray(bad[1])
+    forged[33] ^= 1
+    bad[1] = bytes(forged)
+    with pytest.raises(ValueError):
+        sigs.prove_set(case[3][0], bad, votes[1], case[4])
+    # a flag without a signature (the unsigned slot claimed as signed)
+    with pytest.raises(ValueError):
+        sigs.prove_set(case[3][0], votes[0][:4] + [bytes(64)], votes[1], [True] * 5)
+    # one validator votes for ANOTHER block (validly signed): the node refuses the mixed children
+    from importlib import import_module
+    ec = import_module(graft.PKG_NAME + ".ed25519_circuit")
+    other_msgs = list(votes[1])
+    other_msgs[2] = sigs.vote_bytes(hashlib.sha256(b"another block").digest(), 2)
+    other_sigs = list(votes[0])
+    other_sigs[2] = ec.keypair_and_sign(seeds[2], other_msgs[2])[1]
+    with pytest.raises(ValueError):
+        sigs.prove_set(case[3][0], other_sigs, other_msgs, case[4])
+    # ... and votes that all name another block fold, but cannot be joined with this skip
+    h2 = hashlib.sha256(b"another block").digest()
+    m2 = [sigs.vote_bytes(h2, i) for i in range(5)]
+    s2 = [ec.keypair_and_sign(seeds[i], m2[i])[1] if case[4][i] else None for i in range(5)]
+    with pytest.raises(ValueError):
+        mr.prove_skip(*case, votes=(s2, m2))
+    mr.free()
+    sigs.free()
