@@ -85,7 +85,7 @@ class CombinedSkipMapReduce:
         proofs, specs = [chain_root], [chain_spec]
         if sig_root is not None:
             proofs.append(sig_root)
-            specs.append(dict(leaf_key=sig_key, n_public=self.sigs.N_PUBLIC, child_is_recursion=True))
+            specs.append(dict(leaf_key=sig_key, n_public=self.sigs.N_PUBLIC, child_is_recursion=True, child_sha=False))
         rp = vc.RecursionProgram(self.prover, proofs, chain_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80,
                                  n_public=HeaderChainMapReduce.N_PUBLIC, cap_height=1, child_is_recursion=chain_is_node, child_sha=True,
                                  combine=combine, builder_wires=SHA_GATE_WIRES, specs=specs)

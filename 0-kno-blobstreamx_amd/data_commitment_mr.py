@@ -76,6 +76,10 @@ class DataCommitmentMapReduce:
         """the circuit flags of the proofs a level-`level` node verifies: here leaves hash their tuples with Poseidon rows, nodes always have them"""
         return True
 
+    def _child_has_sha_rows(self, level):
+        """do the proofs a level-`level` node verifies come from circuits with SHA-256 / ADD rows (here: always — leaves hash, nodes combine roots)"""
+        return True
+
     def _child_n_public(self, level):
         """public inputs of the proofs a level-`level` node verifies (the same at every level here)"""
         return self.N_PUBLIC
@@ -149,7 +153,7 @@ class DataCommitmentMapReduce:
         if k not in self.nodes:
             t0 = time.perf_counter()
             self.nodes[k] = vc.RecursionProgram(self.prover, proofs, child_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80,
-                                                n_public=self._child_n_public(level), cap_height=1, child_is_recursion=self._child_has_poseidon_rows(level), child_sha=True,
+                                                n_public=self._child_n_public(level), cap_height=1, child_is_recursion=self._child_has_poseidon_rows(level), child_sha=self._child_has_sha_rows(level),
                                                 combine=self._combine_for(span), builder_wires=SHA_GATE_WIRES)
             self.record_seconds[f"node_level{level}_fan{len(proofs)}"] = round(time.perf_counter() - t0, 3)
         return self.nodes[k]

@@ -43,6 +43,9 @@ class SignatureSetMapReduce(DataCommitmentMapReduce):
     def _child_has_poseidon_rows(self, level):
         return level > 1                             # a signature leaf is arithmetic gates and ADD rows only
 
+    def _child_has_sha_rows(self, level):
+        return level == 1                            # ... and the nodes above have Poseidon rows and arithmetic only
+
     def _combine_for(self, span):
         leaf_children = span == 1
 
