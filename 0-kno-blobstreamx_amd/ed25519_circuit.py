@@ -222,13 +222,22 @@ def _ed_add(P1, P2):
 
 
 def _ed_mul(s, Pt):
-    acc = (0, 1)
+    """[s]Pt for an affine point, in extended coordinates (one inversion at the end): host-side helper for tables, tests and synthetic keys"""
+    def add(A, B):
+        a = (A[1] - A[0]) * (B[1] - B[0]) % Q
+        b = (A[1] + A[0]) * (B[1] + B[0]) % Q
+        c = 2 * D * A[3] * B[3] % Q
+        d = 2 * A[2] * B[2] % Q
+        e, f, g, h = b - a, d - c, d + c, b + a
+        return (e * f % Q, g * h % Q, f * g % Q, e * h % Q)
+    acc, cur = (0, 1, 1, 0), (Pt[0], Pt[1], 1, Pt[0] * Pt[1] % Q)
     while s:
         if s & 1:
-            acc = _ed_add(acc, Pt)
-        Pt = _ed_add(Pt, Pt)
+            acc = add(acc, cur)
+        cur = add(cur, cur)
         s >>= 1
-    return acc
+    zi = pow(acc[2], Q - 2, Q)
+    return (acc[0] * zi % Q, acc[1] * zi % Q)
 
 
 def recover_x(y, sign):
