@@ -127,24 +127,45 @@ class DataCommitmentMapReduce:
         dw, public = self.leaf_program.device_witness(prover, vals, reuse=True)          # the program's own buffer: no allocation per leaf
         return circuit.prove_(dw, self.nq, self.pw, public=public), public
 
+    def _map_inputs(self, inputs_list):
+        """leaf proofs for a list of input vectors of the recorded leaf program, in order.  The witness programs are evaluated on a pool of host
+        threads of their own (glp_witness_eval releases the GIL; a 1.3 M-variable signature leaf takes ~25 ms on one core) while the provers —
+        this object's prover and its map_provers, one host thread each — place the witnesses and prove: the GPU never waits for a witness after the
+        first ones.  A witness that does not satisfy the circuit raises ValueError from here."""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        n_workers = 1 + len(self.map_provers)
+        n_eval = max(1, min(len(inputs_list), (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 2) - n_workers, 12))
+        evaluate = lambda inp: self.leaf_program.evaluate(self.consts, inp, threads=1)
+        with ThreadPoolExecutor(n_eval) as epool:
+            futs = [epool.submit(evaluate, inp) for inp in inputs_list]
+
+            def work(w):
+                if w:
+                    self.map_provers[w - 1].bind_thread()
+                prover, circuit = (self.prover, self.leaf_circuit) if w == 0 else (self.map_provers[w - 1], self.map_circuits[w - 1])
+                out = []
+                for i in range(w, len(inputs_list), n_workers):
+                    dw, public = self.leaf_program.device_witness(prover, futs[i].result(), reuse=True)
+                    out.append((i, circuit.prove_(dw, self.nq, self.pw, public=public)))
+                return out
+            try:
+                if n_workers == 1 or len(inputs_list) == 1:
+                    done = work(0)
+                else:
+                    with ThreadPoolExecutor(n_workers) as ex:
+                        done = sorted((p for f in [ex.submit(work, w) for w in range(n_workers)] for p in f.result()), key=lambda t: t[0])
+            finally:
+                for f in futs:
+                    f.cancel()
+        return [p for _, p in done]
+
     def prove_leaves(self, heights, data_roots):
         """the Map step of a (sub)range: its leaf proofs in order, on every prover this object has"""
         if self.leaf_program is None:
             self._record_leaf()
         B = self.leaf_blocks
-        starts = list(range(0, len(heights), B))
-        n_workers = 1 + len(self.map_provers)
-        if n_workers == 1 or len(starts) == 1:
-            return [self.prove_leaf(heights[k:k + B], data_roots[k:k + B])[0] for k in starts]
-        from concurrent.futures import ThreadPoolExecutor
-
-        def work(w):
-            if w:
-                self.map_provers[w - 1].bind_thread()
-            return [(k, self.prove_leaf(heights[k:k + B], data_roots[k:k + B], which=w)[0]) for k in starts[w::n_workers]]
-        with ThreadPoolExecutor(n_workers) as ex:
-            done = sorted((p for f in [ex.submit(work, w) for w in range(n_workers)] for p in f.result()), key=lambda t: t[0])
-        return [p for _, p in done]
+        return self._map_inputs([[w for h, r in zip(heights[k:k + B], data_roots[k:k + B]) for w in tuple_words(h, r)] for k in range(0, len(heights), B)])
 
     # ---- Reduce -------------------------------------------------------------------------------------------------------------------
     def _node(self, level, proofs, child_key, span=0):
@@ -450,19 +471,10 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
     def _map_chain(self, hashes, first_height, headers, lo, hi):
         """leaf proofs of headers[lo:hi] (a whole number of leaves), on every prover this object has; hashes[k] = hash of the header BEFORE header k"""
         B = self.leaf_blocks
-        jobs = [(hashes[k], first_height + k, headers[k:k + B]) for k in range(lo, hi, B)]
-        n_workers = 1 + len(self.map_provers)
-        if n_workers == 1 or len(jobs) == 1:
-            return [self.prove_leaf(*j)[0] for j in jobs]
-        from concurrent.futures import ThreadPoolExecutor
-
-        def work(w):
-            if w:
-                self.map_provers[w - 1].bind_thread()
-            return [(i, self.prove_leaf(*jobs[i], which=w)[0]) for i in range(w, len(jobs), n_workers)]
-        with ThreadPoolExecutor(n_workers) as ex:
-            done = sorted((p for f in [ex.submit(work, w) for w in range(n_workers)] for p in f.result()), key=lambda t: t[0])
-        return [p for _, p in done]
+        for k in range(lo, hi, B):
+            if any(tuple(len(bytes(f)) for f in h) != self.field_lengths for h in headers[k:k + B]):
+                raise ValueError("a leaf takes leaf_headers headers whose field encodings have the recorded lengths")
+        return self._map_inputs([_chain_leaf_inputs(hashes[k], first_height + k, headers[k:k + B], self.n_groups) for k in range(lo, hi, B)])
 
     def prove_chain_distributed(self, start_hash, first_height, headers, device=None, comm=None):
         """prove_chain with the work spread over the ranks (mapreduce.reduce_tree_distributed): rank r proves and folds the r-th contiguous part of

@@ -110,19 +110,10 @@ class SignatureSetMapReduce(DataCommitmentMapReduce):
         return (list(pubkeys) + [bytes(32)] * pad, list(signatures) + [None] * pad, list(msgs) + [msgs[0]] * pad, [bool(f) for f in flags] + [False] * pad)
 
     def _map(self, slots, lo, hi):
-        jobs = [(slots[0][i], slots[1][i], slots[2][i], slots[3][i]) for i in range(lo, hi)]
-        n_workers = 1 + len(self.map_provers)
-        if n_workers == 1 or len(jobs) == 1:
-            return [self.prove_leaf(*j)[0] for j in jobs]
-        from concurrent.futures import ThreadPoolExecutor
-
-        def work(w):
-            if w:
-                self.map_provers[w - 1].bind_thread()
-            return [(i, self.prove_leaf(*jobs[i], which=w)[0]) for i in range(w, len(jobs), n_workers)]
-        with ThreadPoolExecutor(n_workers) as ex:
-            done = sorted((p for f in [ex.submit(work, w) for w in range(n_workers)] for p in f.result()), key=lambda t: t[0])
-        return [p for _, p in done]
+        for i in range(lo, hi):
+            if len(bytes(slots[2][i])) != self.msg_len or len(bytes(slots[0][i])) != 32:
+                raise ValueError("vote bytes / key of another length than this circuit was recorded for")
+        return self._map_inputs([witness_inputs(slots[0][i], slots[1][i] if slots[3][i] else bytes(64), slots[2][i], slots[3][i]) for i in range(lo, hi)])
 
     def prove_set(self, pubkeys, signatures, msgs, flags):
         """one proof for a validator set's signatures: public = block hash (8 words), signer digest (4 words).  signatures[i] may be None where
