@@ -19,8 +19,10 @@ Statements (all build-defined, NOT upstream's circuits; encodings are public spe
   ``step_statement`` / ``skip_statement``   the light-client step (chain link through last_block_id, one set, > 2/3) and skip (two sets, > 2/3 of
                                   the target power, > 1/3 of the trusted power) statements, with a SIGNER DIGEST as public input
   ``combined_skip_circuit``       skip + header chain + data commitment in one circuit (CombinedSkip's shape minus Ed25519)
-Ed25519 is NOT constrained anywhere: the flags saying who signed are witnesses, exposed through the signer digest so that
-``blobstream.verify_signers`` checks exactly those signatures natively (GPU kernel).  data_commitment_mr.py builds the range MapReduce on top.
+In THESE single-circuit statements the flags saying who signed are witnesses, exposed through the signer digest (a Poseidon tree over one leaf per
+validator slot) so that ``blobstream.verify_signers`` can check exactly those signatures natively.  The MapReduce form verifies them IN-CIRCUIT:
+signature_mr.py proves one ed25519_circuit leaf per slot and folds the slots into the same digest, combined_skip_mr.py equates the two (round 3).
+data_commitment_mr.py builds the range MapReduce on top.
 """
 import struct
 

@@ -191,3 +191,26 @@ def test_combined_skip_with_the_signatures_in_circuit(prover, oracle, pkg):
         mr.prove_skip(*case, votes=(s2, m2))
     mr.free()
     sigs.free()
+
+
+@pytest.mark.gpu
+def test_combined_step_shape_with_signatures(prover, oracle, pkg):
+    """BASELINE configs[1]'s statement (CombinedStep: ONE header after the trusted one) through the same machinery: a one-header chain leaf verified
+    directly by the outer circuit (no chain nodes), one validator set behind both headers, the signatures in-circuit.  target block = trusted + 1."""
+    cs, dm, gd, bs = _mods()
+    sm = importlib.import_module(graft.PKG_NAME + ".signature_mr")
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    sigs = sm.SignatureSetMapReduce(prover, consts, msg_len=48, hash_offset=8, fan_in=2, num_queries=6, pow_bits=4)
+    st = cs.CombinedSkipMapReduce(prover, consts, skip=1, batch=1, fan_in=2, num_queries=6, pow_bits=4, max_skip=100, signatures=sigs)
+    *case, seeds = st.synthetic_case(4, 4, [0, 1, 2, 3], trusted_height=2_600_000, power_groups=3, seed=21, real_keys=True)
+    out = st.prove_skip(*case, votes=st.synthetic_votes(case, seeds))
+    want = _expected(dm, gd, consts, tuple(case), 1)
+    assert out["leaves"] == 1 and out["levels"] == [] and {k: out[k] for k in want} == want
+    assert want["target_block"] == want["trusted_block"] + 1
+    assert st.verify(out["root_proof"], out["key"], **want), prover.last_reject
+    pref.verify_plonk(out["root_proof"], oracle, pos_consts=consts, public=out["public"])
+    assert not st.verify(out["root_proof"], out["key"], **dict(want, commitment=bytes(32)))
+    st.free()
+    sigs.free()
