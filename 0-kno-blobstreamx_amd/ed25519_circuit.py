@@ -525,11 +525,13 @@ def dummy_signature(msg_len):
     return _DUMMY[msg_len]
 
 
-def witness_inputs(pub32, sig64, msg, flag=None):
+def witness_inputs(pub32, sig64, msg, flag=None, record=None):
     """the input vector of a program recorded from verify_statement for a message of this length, in the order the statement creates its free
     variables: [with a flag: the flag, the validator's key bytes, the message bytes, then for the VERIFIED triple — the validator's own when the
     flag is 1, dummy_signature's when it is 0 —] A bytes, R bytes, S bytes, message bytes [without a flag only], then the limbs of x_A, x_R, of
-    the quotient t and of k = SHA-512(R || A || M) mod L.  ValueError when A or R does not decode (no witness exists)."""
+    the quotient t and of k = SHA-512(R || A || M) mod L.  ValueError when A or R does not decode (no witness exists).
+    record: the 37-word record of the GPU witness kernel for the VERIFIED triple (glp_ed25519_witness: verdict, k, decoded A and R ...): x_A, x_R
+    and k are then taken from the device's computation instead of being recomputed with Python integers (the circuit checks them either way)."""
     pub32, msg = bytes(pub32), bytes(msg)
     head = []
     if flag is not None:
@@ -539,12 +541,19 @@ def witness_inputs(pub32, sig64, msg, flag=None):
     sig64 = bytes(sig64)
     if len(sig64) != 64:
         raise ValueError("a signature is 64 bytes")
-    ya, yr = int.from_bytes(pub32, "little"), int.from_bytes(sig64[:32], "little")
-    xa, xr = recover_x(ya & ((1 << 255) - 1), ya >> 255), recover_x(yr & ((1 << 255) - 1), yr >> 255)
-    if xa is None or xr is None:
-        raise ValueError("the public key or R does not decode to a curve point")
     h = int.from_bytes(hashlib.sha512(sig64[:32] + pub32 + msg).digest(), "little")
-    t, k = divmod(h, ELL)
+    if record is None:
+        ya, yr = int.from_bytes(pub32, "little"), int.from_bytes(sig64[:32], "little")
+        xa, xr = recover_x(ya & ((1 << 255) - 1), ya >> 255), recover_x(yr & ((1 << 255) - 1), yr >> 255)
+        if xa is None or xr is None:
+            raise ValueError("the public key or R does not decode to a curve point")
+        t, k = divmod(h, ELL)
+    else:
+        word = lambda o: sum(int(record[o + j]) << (64 * j) for j in range(4))
+        if not int(record[0]):
+            raise ValueError("the GPU witness kernel rejects this signature: no witness exists")
+        k, xa, xr = word(1), word(5), word(13)
+        t = (h - k) // ELL                                                    # the circuit checks h = t * L + k: a wrong k from the device cannot pass
     body = (list(pub32) if flag is None else []) + list(sig64[:32]) + list(sig64[32:]) + (list(msg) if flag is None else [])
     return head + body + limbs_of(xa) + limbs_of(xr) + limbs_of(t) + limbs_of(k)
 

@@ -110,10 +110,23 @@ class SignatureSetMapReduce(DataCommitmentMapReduce):
         return (list(pubkeys) + [bytes(32)] * pad, list(signatures) + [None] * pad, list(msgs) + [msgs[0]] * pad, [bool(f) for f in flags] + [False] * pad)
 
     def _map(self, slots, lo, hi):
+        """leaf proofs of slots [lo, hi).  The per-signature hints of the circuit witness — the decoded x coordinates of A and R and
+        k = SHA-512(R || A || M) mod L — come from ONE launch of the GPU witness kernel over the slots' verified triples (glp_ed25519_witness, the
+        kernel north_star names for this job); a flagged slot the kernel rejects is refused here, before any witness program runs."""
+        from .ed25519_circuit import dummy_signature
         for i in range(lo, hi):
             if len(bytes(slots[2][i])) != self.msg_len or len(bytes(slots[0][i])) != 32:
                 raise ValueError("vote bytes / key of another length than this circuit was recorded for")
-        return self._map_inputs([witness_inputs(slots[0][i], slots[1][i] if slots[3][i] else bytes(64), slots[2][i], slots[3][i]) for i in range(lo, hi)])
+        d_pub, d_sig, d_msg = dummy_signature(self.msg_len)
+        triples = [(slots[0][i], slots[1][i], slots[2][i]) if slots[3][i] else (d_pub, d_sig, d_msg) for i in range(lo, hi)]
+        if any(t[1] is None or len(bytes(t[1])) != 64 for t in triples):
+            raise ValueError("a flagged slot has no 64-byte signature")
+        recs = self.prover.ed25519_witness([bytes(t[0]) for t in triples], [bytes(t[1]) for t in triples], [bytes(t[2]) for t in triples])
+        bad = [lo + j for j in range(len(triples)) if not int(recs[j][0])]
+        if bad:
+            raise ValueError(f"the signatures of slots {bad[:8]} do not verify (GPU witness kernel)")
+        return self._map_inputs([witness_inputs(slots[0][i], slots[1][i] if slots[3][i] else bytes(64), slots[2][i], slots[3][i], record=recs[i - lo])
+                                 for i in range(lo, hi)])
 
     def prove_set(self, pubkeys, signatures, msgs, flags):
         """one proof for a validator set's signatures: public = block hash (8 words), signer digest (4 words).  signatures[i] may be None where
