@@ -140,7 +140,7 @@ def test_emulated_ntt_strided_batch(emu, oracle):
 
 def test_emulated_kernels_under_the_alternative_two_adic_generator():
     """the two-adic generator is a BUILD parameter (csrc/gl_field.cuh): the kernel bodies compiled on 7277203076849721926 (w_64 = 2^3: other
-    shift twiddles in every butterfly, other tables) against the oracle switched to the same generator — every third NTT case and the coset
+    shift twiddles in every butterfly, other tables) against the oracle switched to the same generator — every fifth NTT case and the coset
     LDE cases, in a child process (the emulation library and the product library it reads the generator from are selected by environment)."""
     import subprocess
     import sys
@@ -150,7 +150,7 @@ def test_emulated_kernels_under_the_alternative_two_adic_generator():
         pytest.skip("this IS the alternative-generator run")
     if not os.path.exists(alt):
         pytest.skip("lib/libglprover_altgen.so not built (__graft_entry__.build() makes it)")
-    env = dict(os.environ, GLP_LIB=alt, GLP_EMU_ALTGEN="1", GLP_EMU_CASE_STRIDE="3")
+    env = dict(os.environ, GLP_LIB=alt, GLP_EMU_ALTGEN="1", GLP_EMU_CASE_STRIDE="5")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k", "emulated_ntt or lde"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=os.path.dirname(here))
     assert r.returncode == 0, r.stdout[-3000:]
