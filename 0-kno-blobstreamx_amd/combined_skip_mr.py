@@ -238,6 +238,21 @@ class CombinedSkipMapReduce:
         *case, seeds = self.synthetic_case(n_trusted, n_target, trusted_index, power_groups=power_groups, real_keys=True)
         return self.prove_skip(*case, votes=self.synthetic_votes(case, seeds))["key"]
 
+    @staticmethod
+    def evm_values(public):
+        """the final proof's statement in the packed form a contract reads / writes ([RECALLED] plonky2x evm_read / evm_write of the skip circuit:
+        input = (trusted_block u64, trusted_header_hash bytes32, target_block u64), output = (target_header_hash bytes32, data_commitment
+        bytes32), big-endian, blobstream.pack_skip_inputs / pack_outputs) — and the check that the proof's public inputs ARE those bytes' 32-bit
+        words (block numbers as single field elements, the signer digest in between).  Returns (input bytes, output bytes)."""
+        from .blobstream import pack_outputs, pack_skip_inputs, public_words
+        be = lambda ws: b"".join(struct.pack(">I", int(v)) for v in ws)
+        trusted_hash, target_hash, commitment = be(public[:8]), be(public[8:16]), be(public[22:30])
+        inp = pack_skip_inputs(int(public[20]), trusted_hash, int(public[21]))
+        outp = pack_outputs(target_hash, commitment)
+        assert public_words(outp) == [int(v) for v in public[8:16]] + [int(v) for v in public[22:30]]
+        assert public_words(trusted_hash) == [int(v) for v in public[:8]]
+        return inp, outp
+
     def verify(self, root_proof, key, trusted_hash, target_hash, signer_digest, trusted_block, target_block, commitment):
         public = list(struct.unpack(">8I", bytes(trusted_hash))) + list(struct.unpack(">8I", bytes(target_hash))) + [int(v) for v in signer_digest] + \
             [int(trusted_block), int(target_block)] + list(struct.unpack(">8I", bytes(commitment)))

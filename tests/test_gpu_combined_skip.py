@@ -51,6 +51,10 @@ def test_combined_skip_small_tree_and_negative_cases(prover, oracle, pkg):
     assert out["leaves"] == 4 and {k: out[k] for k in want} == want and len(out["public"]) == 30
     assert mr.verify(out["root_proof"], out["key"], **want), prover.last_reject
     pref.verify_plonk(out["root_proof"], oracle, pos_consts=consts, public=out["public"])
+    # the statement in the packed form a contract reads and writes (big-endian u64 / bytes32)
+    inp, outp = cs.CombinedSkipMapReduce.evm_values(out["public"])
+    assert inp == struct.pack(">Q", want["trusted_block"]) + want["trusted_hash"] + struct.pack(">Q", want["target_block"])
+    assert outp == want["target_hash"] + want["commitment"]
     for k, v in (("trusted_block", want["trusted_block"] + 1), ("commitment", bytes(32)), ("target_hash", want["trusted_hash"]),
                  ("signer_digest", [1, 2, 3, 4])):
         assert not mr.verify(out["root_proof"], out["key"], **dict(want, **{k: v}))
