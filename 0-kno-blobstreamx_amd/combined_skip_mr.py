@@ -46,7 +46,7 @@ class CombinedSkipMapReduce:
         self._own_chain = chain is None
         self.chain = chain if chain is not None else HeaderChainMapReduce(
             prover, poseidon_consts, leaf_headers=batch, fan_in=fan_in, num_queries=num_queries, pow_bits=pow_bits, map_provers=map_provers,
-            height_varint_bytes=height_varint_bytes, field_lengths=field_lengths)
+            height_varint_bytes=height_varint_bytes, field_lengths=field_lengths, defer_commitment=(batch >= 8 and skip >= 2 * batch))
         if (self.chain.leaf_blocks, self.chain.nq, self.chain.pw) != (batch, num_queries, pow_bits):
             raise ValueError("the shared chain object has other parameters")
         self.outer = {}                  # (chain root key, trusted_index, ..., signature root key) -> RecursionProgram

@@ -317,11 +317,26 @@ def _varint_groups(value, n_groups):
     return groups
 
 
-def _chain_leaf_statement(b, g, start_hash_words, first_height, headers, n_groups):
+def _tuple_leaf(b, g, hk, data_words, c2_15):
+    """the RFC 6962 leaf hash of abi.encode(height, data_hash) for a height VARIABLE hk (< 2^49) and the data hash's 8 word variables: the height is
+    the low two 32-bit words of a uint256, split with hi < 2^17 shown (without that bound hi * 2^32 + lo == hk has a second solution mod p)"""
+    lo, hi = b.bit_field(hk, 0, 32), b.bit_field(hk, 32, 17)
+    b.range32(lo)
+    b.range32(hi)
+    b.range32(b.arith(1, 0, 0, hi, c2_15, hi))                                          # hi < 2^17: hi * 2^32 + lo < 2^49 cannot wrap mod p, so
+    b.assert_equal(b.arith(1, 1, 0, hi, g.c2_32, lo), hk)                                # (hi, lo) is THE split of hk (no hi = 2^32 - 1, lo = hk + 1 alias)
+    zero = b.constant(0)
+    return g.hash_prefixed_64(0x00, [zero] * 6 + [hi, lo] + list(data_words))
+
+
+def _chain_leaf_statement(b, g, start_hash_words, first_height, headers, n_groups, defer_commitment=False):
     """one leaf of the chain MapReduce on builder b: `headers` (field encodings) follow a header whose hash is start_hash (INPUT words); header k
     sits at height first_height + k (a variable + constant; its Int64Value field encoding is built in-circuit from range-checked 7-bit groups, whose
     number n_groups is a constant of the circuit), links to its predecessor's hash through last_block_id, and its data_hash feeds tuple k.
-    Returns the leaf's public inputs: start hash (8), end hash (8), subtree root R (8), first height (1)."""
+    Returns the leaf's public inputs: start hash (8), end hash (8), subtree root R (8), first height (1).
+    defer_commitment: the leaf does NOT hash its tuples; it exposes every header's data hash instead — start hash (8), end hash (8), first
+    height (1), then 8 words per header — and the level-1 NODE hashes the tuples of its children (30 of an 8-header leaf's 368 compressions are
+    tuple hashing: without them the leaf fits 2^16 rows instead of 2^17, and the node circuit has the room)."""
     from .gadgets import header_hash_statement
     start = [b.range32(b.var(v)) for v in start_hash_words]
     first = b.var(first_height)
@@ -347,14 +362,10 @@ def _chain_leaf_statement(b, g, start_hash_words, first_height, headers, n_group
         data_hash = [g.byte(b.var(v)) for v in bytes(fields[6])[2:]]
         block_id = wrap(prev) + [g.byte(b.var(v)) for v in bytes(fields[4])[34:]]
         prev = header_hash_statement(b, g, fields, bound={2: hfield, 4: block_id, 6: [b.constant(0x0a), b.constant(0x20)] + data_hash})
-        lo, hi = b.bit_field(hk, 0, 32), b.bit_field(hk, 32, 17)                         # the height as the low two words of a uint256
-        b.range32(lo)
-        b.range32(hi)
-        b.range32(b.arith(1, 0, 0, hi, c2_15, hi))                                      # hi < 2^17: hi * 2^32 + lo < 2^49 cannot wrap mod p, so
-        b.assert_equal(b.arith(1, 1, 0, hi, g.c2_32, lo), hk)                            # (hi, lo) is THE split of hk (no hi = 2^32 - 1, lo = hk + 1 alias)
-        zero = b.constant(0)
         root_words = [g.word_from_bytes(data_hash[j:j + 4]) for j in range(0, 32, 4)]
-        leaves.append(g.hash_prefixed_64(0x00, [zero] * 6 + [hi, lo] + root_words))
+        leaves.append(root_words if defer_commitment else _tuple_leaf(b, g, hk, root_words, c2_15))
+    if defer_commitment:
+        return start + prev + [first] + [w for ws in leaves for w in ws]
     while len(leaves) > 1:
         leaves = [g.hash_prefixed_64(0x01, leaves[j] + leaves[j + 1]) for j in range(0, len(leaves), 2)]
     return start + prev + leaves[0] + [first]
@@ -384,25 +395,51 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
     N_PUBLIC = 25
 
     def __init__(self, prover, poseidon_consts, leaf_headers=8, fan_in=8, num_queries=28, pow_bits=16, map_provers=(), height_varint_bytes=4,
-                 field_lengths=(4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22)):
+                 field_lengths=(4, 12, 5, 13, 72, 34, 34, 34, 34, 34, 34, 34, 34, 22), defer_commitment=None):
+        """defer_commitment (default: leaves of 8 or more headers): the leaves expose their headers' data hashes and the LEVEL-1 NODES hash the
+        (height, data_hash) tuples and the leaf subtrees — round 3: an 8-header leaf is 368 compressions x 178 rows = 2.7k rows past 2^16; without
+        its 30 tuple / subtree compressions it fits 2^16 rows (half the leaf proof), and the node circuit (75k of 131k rows used) has the room.
+        The statement of every node — hence of the root — is unchanged; a chain of ONE leaf has no node and is refused in this mode."""
         super().__init__(prover, poseidon_consts, leaf_blocks=leaf_headers, fan_in=fan_in, num_queries=num_queries, pow_bits=pow_bits,
                          map_provers=map_provers)
+        self.defer = (leaf_headers >= 8) if defer_commitment is None else bool(defer_commitment)
+        if self.defer and leaf_headers & (leaf_headers - 1):
+            raise ValueError("deferred tuple hashing needs a power-of-two number of headers per leaf")
         if not 1 <= height_varint_bytes <= 7:
             raise ValueError("heights are below 2^49: at most 7 varint bytes")
         self.n_groups, self.field_lengths = height_varint_bytes, tuple(field_lengths)
 
+    def _child_n_public(self, level):
+        return 17 + 8 * self.leaf_blocks if (level == 1 and self.defer) else self.N_PUBLIC
+
     def _combine_for(self, span):
+        deferred_leaves = self.defer and span == self.leaf_blocks                    # the children are leaves that expose data hashes, not R
+
         def combine(b, outs):
             g = Sha256Rows(b)
+            first_of = (lambda o: o["public"][16]) if deferred_leaves else (lambda o: o["public"][24])
             for left, right in zip(outs, outs[1:]):
                 for x, y in zip(left["public"][8:16], right["public"][:8]):
                     b.assert_equal(x, y)                                              # right starts where left ended
-                lf = left["public"][24]
-                b.assert_equal(b.arith(0, 1, span, lf, lf, lf), right["public"][24])  # ... and span headers later
-            roots = [o["public"][16:24] for o in outs]
+                lf = first_of(left)
+                b.assert_equal(b.arith(0, 1, span, lf, lf, lf), first_of(right))      # ... and span headers later
+            if deferred_leaves:
+                c2_15 = b.constant(1 << 15)
+                roots = []
+                for o in outs:                                                        # the child's tuples, hashed HERE: heights first .. first + B - 1
+                    first, words = o["public"][16], o["public"][17:]
+                    lv = []
+                    for k in range(self.leaf_blocks):
+                        hk = first if k == 0 else b.arith(0, 1, k, first, first, first)
+                        lv.append(_tuple_leaf(b, g, hk, words[8 * k: 8 * k + 8], c2_15))
+                    while len(lv) > 1:
+                        lv = [g.hash_prefixed_64(0x01, lv[j] + lv[j + 1]) for j in range(0, len(lv), 2)]
+                    roots.append(lv[0])
+            else:
+                roots = [o["public"][16:24] for o in outs]
             while len(roots) > 1:
                 roots = [g.hash_prefixed_64(0x01, roots[k] + roots[k + 1]) for k in range(0, len(roots), 2)]
-            return outs[0]["public"][:8] + outs[-1]["public"][8:16] + roots[0] + [outs[0]["public"][24]]
+            return outs[0]["public"][:8] + outs[-1]["public"][8:16] + roots[0] + [first_of(outs[0])]
         return combine
 
     def _child_has_poseidon_rows(self, level):
@@ -415,7 +452,7 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
         sample_height = 1 << (7 * (self.n_groups - 1))                                   # the smallest height with this many varint bytes
         fields = [bytes(n) for n in self.field_lengths]
         fields[6] = b"\x0a\x20" + bytes(32)
-        for v in _chain_leaf_statement(b, g, [0] * 8, sample_height, [fields] * self.leaf_blocks, self.n_groups):
+        for v in _chain_leaf_statement(b, g, [0] * 8, sample_height, [fields] * self.leaf_blocks, self.n_groups, self.defer):
             b.public_input(v)
         self.leaf_program = b.program()
         self.leaf_circuit = self.leaf_program.setup(self.prover)
@@ -459,6 +496,8 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
         t1 = time.perf_counter()
         levels = []
         if len(leaves) == 1:
+            if self.defer:
+                raise ValueError("with deferred tuple hashing a chain needs at least two leaves (the level-1 node hashes the tuples)")
             root_proof, key = leaves[0], self.leaf_circuit.cap()
             public = [int(v) for v in importlib.import_module(__package__).proof_public_inputs(root_proof)]
         else:
@@ -496,6 +535,8 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
             leaves = self._map_chain(hashes, first_height, headers, rank * per, (rank + 1) * per)
             state["map_seconds"] = round(time.perf_counter() - t0, 4)
             if len(leaves) == 1:
+                if self.defer:
+                    raise ValueError("with deferred tuple hashing every rank needs at least two leaves")
                 state.update(key=self.leaf_circuit.cap(), level=1, public=None, span=B)
                 return leaves[0]
             proof, public, key, level = self.reduce(leaves, levels)

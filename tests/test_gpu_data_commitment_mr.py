@@ -183,6 +183,23 @@ def test_header_chain_data_commitment_by_mapreduce(prover, oracle, pkg):
     assert not np.array_equal(vr.expected_key(4), vkey)            # a chain of another length is another circuit tower
     vr.free()
     p2.close()
+    # round 3: the DEFERRED form (what 8-header leaves use): the leaves expose their headers' data hashes, the level-1 nodes hash the tuples — the
+    # root states exactly the same thing (same public inputs), through other circuits (another key)
+    md = dm.HeaderChainMapReduce(prover, consts, leaf_headers=2, fan_in=2, num_queries=6, pow_bits=4, defer_commitment=True)
+    outd = md.prove_chain(start, first, headers)
+    assert outd["public"] == out["public"] and outd["end_hash"] == end and outd["commitment"] == want and not np.array_equal(outd["key"], out["key"])
+    assert md.verify_chain(outd["root_proof"], outd["key"], start, end, want, first), prover.last_reject
+    assert len(pkg.proof_public_inputs(md.prove_leaf(start, first, headers[:2])[0])) == 17 + 16
+    d0, _ = md.prove_leaf(start, first, headers[:2])
+    d1, _ = md.prove_leaf(mid, first + 2, headers[2:4])
+    with pytest.raises(ValueError):
+        md.reduce([d1, d0])                                                     # not adjacent
+    d1_wrong, _ = md.prove_leaf(mid, first + 3, headers[2:4])
+    with pytest.raises(ValueError):
+        md.reduce([d0, d1_wrong])                                               # a leaf at another height does not connect
+    with pytest.raises(ValueError):
+        md.prove_chain(start, first, headers[:2])                               # one leaf: no node to hash its tuples
+    md.free()
     # another chain through the recorded programs
     rec_before = dict(mr.record_seconds)
     s2 = hashlib.sha256(b"another").digest()
