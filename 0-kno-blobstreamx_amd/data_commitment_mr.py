@@ -84,6 +84,10 @@ class DataCommitmentMapReduce:
         """public inputs of the proofs a level-`level` node verifies (the same at every level here)"""
         return self.N_PUBLIC
 
+    def _child_n_routed(self, level):
+        """routed wires of the circuits a level-`level` node verifies (80 of 144 everywhere here)"""
+        return 80
+
     def __init__(self, prover, poseidon_consts, leaf_blocks=64, fan_in=8, num_queries=28, pow_bits=16, map_provers=()):
         """map_provers: further Provers on the same GPU (their Poseidon constants set): the Map step then proves leaves on all of them at once,
         one host thread each (the latency-bound phases of one leaf proof overlap the throughput-bound phases of another, as in mapreduce.py)"""
@@ -173,7 +177,7 @@ class DataCommitmentMapReduce:
         k = (level, len(proofs), span, bytes(np.ascontiguousarray(child_key, dtype=np.uint64)))      # the child circuit's key is a CONSTANT of the node circuit
         if k not in self.nodes:
             t0 = time.perf_counter()
-            self.nodes[k] = vc.RecursionProgram(self.prover, proofs, child_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80,
+            self.nodes[k] = vc.RecursionProgram(self.prover, proofs, child_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=self._child_n_routed(level),
                                                 n_public=self._child_n_public(level), cap_height=1, child_is_recursion=self._child_has_poseidon_rows(level), child_sha=self._child_has_sha_rows(level),
                                                 combine=self._combine_for(span), builder_wires=SHA_GATE_WIRES)
             self.record_seconds[f"node_level{level}_fan{len(proofs)}"] = round(time.perf_counter() - t0, 3)

@@ -361,6 +361,30 @@ class Edwards:
             acc = self.add_niels(acc, N)
         return acc
 
+    def table16(self, Pt):
+        """the Niels forms of [0]Pt .. [15]Pt"""
+        f = self.f
+        n1 = self.to_niels(Pt)
+        mults = [self.identity(), Pt]
+        for _ in range(14):
+            mults.append(self.add_niels(mults[-1], n1))
+        return [(f.const(1), f.const(1), f.const(2), f.const(0)), n1] + [self.to_niels(m) for m in mults[2:]]
+
+    def mul_var2(self, P1, nibbles1, P2, nibbles2):
+        """[a]P1 + [b]P2 on ONE doubling chain (Straus): per 4-bit window four doublings and two table additions"""
+        f = self.f
+        assert len(nibbles1) == len(nibbles2)
+        t1, t2 = self.table16(P1), self.table16(P2)
+        acc = None
+        for bits1, bits2 in zip(reversed(nibbles1), reversed(nibbles2)):
+            if acc is not None:
+                for step in range(4):
+                    acc = self.double(acc, need_t=(step == 3))
+            s1, s2 = self.onehot16(bits1), self.onehot16(bits2)
+            acc = self.add_niels(self.identity() if acc is None else acc, tuple(f.mux(s1, [e[c] for e in t1]) for c in range(4)))
+            acc = self.add_niels(acc, tuple(f.mux(s2, [e[c] for e in t2]) for c in range(4)))
+        return acc
+
     def decode(self, y, x, sign_bit):
         """(x, y) is on the curve, x and y are canonical and x's parity is the sign bit: RFC 8032 §5.1.3 with x as a checked witness"""
         f = self.f
@@ -512,6 +536,37 @@ def _limbs_from_byte_bits(g, byte_bits, n_limbs):
     return [g.pack(flat[LB * i: LB * i + LB]) for i in range(n_limbs) if flat[LB * i: LB * i + LB]]
 
 
+HALF_NIBBLES = 36                     # windows of the half-size scalars: 144 bits (a reduced basis vector longer than that has probability ~2^-36)
+
+
+def half_size_pair(k):
+    """(u, v, neg): u ODD, 0 < u, 0 <= v, both below 2^144, with  u * k = (-v if neg else v)  (mod L).  A short vector of the lattice
+    {(t, r): r = t k mod L} (determinant L ~ 2^252.4) by Lagrange reduction; among the reduced basis and its sum one vector has an odd first
+    coordinate (the lattice contains (1, k)).  With them  [S]B = R + [k]A  <=>  [u S]B = [u]R + [+-v]A  — two 144-bit scalars on ONE shared doubling
+    chain instead of a 253-bit one (u odd and prime-order-invertible: no small-order slack is introduced).  ValueError in the ~2^-36 case that no
+    such pair fits 144 bits."""
+    k %= ELL
+    b1, b2 = (1, k), (0, ELL)
+    norm = lambda v: v[0] * v[0] + v[1] * v[1]
+    if norm(b1) > norm(b2):
+        b1, b2 = b2, b1
+    while True:
+        mu = (b1[0] * b2[0] + b1[1] * b2[1] + norm(b1) // 2) // norm(b1)         # nearest integer of <b1, b2> / <b1, b1>
+        b2 = (b2[0] - mu * b1[0], b2[1] - mu * b1[1])
+        if norm(b2) >= norm(b1):
+            break
+        b1, b2 = b2, b1
+    cands = [c for c in (b1, b2, (b1[0] + b2[0], b1[1] + b2[1]), (b1[0] - b2[0], b1[1] - b2[1])) if c[0] & 1]
+    t, r = min(cands, key=lambda c: max(abs(c[0]), abs(c[1])))
+    if r < 0:
+        t, r = -t, -r
+    u, neg = abs(t), t < 0
+    if u >> (4 * HALF_NIBBLES) or r >> (4 * HALF_NIBBLES):
+        raise ValueError("no half-size scalar pair below 2^144 for this signature (probability ~2^-36)")
+    assert (u * k - (-r if neg else r)) % ELL == 0 and u & 1
+    return u, r, neg
+
+
 _DUMMY = {}
 
 
@@ -525,7 +580,7 @@ def dummy_signature(msg_len):
     return _DUMMY[msg_len]
 
 
-def witness_inputs(pub32, sig64, msg, flag=None, record=None):
+def witness_inputs(pub32, sig64, msg, flag=None, record=None, split_scalars=True):
     """the input vector of a program recorded from verify_statement for a message of this length, in the order the statement creates its free
     variables: [with a flag: the flag, the validator's key bytes, the message bytes, then for the VERIFIED triple — the validator's own when the
     flag is 1, dummy_signature's when it is 0 —] A bytes, R bytes, S bytes, message bytes [without a flag only], then the limbs of x_A, x_R, of
@@ -555,10 +610,18 @@ def witness_inputs(pub32, sig64, msg, flag=None, record=None):
         k, xa, xr = word(1), word(5), word(13)
         t = (h - k) // ELL                                                    # the circuit checks h = t * L + k: a wrong k from the device cannot pass
     body = (list(pub32) if flag is None else []) + list(sig64[:32]) + list(sig64[32:]) + (list(msg) if flag is None else [])
-    return head + body + limbs_of(xa) + limbs_of(xr) + limbs_of(t) + limbs_of(k)
+    out = head + body + limbs_of(xa) + limbs_of(xr) + limbs_of(t) + limbs_of(k)
+    if not split_scalars:
+        return out
+    # the half-size form: u, v, the sign, and the quotients / remainder of  u * S = q1 * L + w  and  u * k -+ v = q2 * L
+    S = int.from_bytes(sig64[32:], "little")
+    u, v, neg = half_size_pair(k)
+    q1, w = divmod(u * S, ELL)
+    q2 = (u * k - (-v if neg else v)) // ELL
+    return out + limbs_of(u, 6) + limbs_of(v, 6) + [1 if neg else 0] + limbs_of(q1, 7) + limbs_of(w) + limbs_of(q2, 7)
 
 
-def verify_statement(b, pub32, sig64, msg, flag=None):
+def verify_statement(b, pub32, sig64, msg, flag=None, split_scalars=True):
     """Lay down, on builder b (144 wires: the range checks use ADD rows), the verification of ONE Ed25519 signature (RFC 8032 §5.1.7, equation
     [S]B = R + [k]A).  Free inputs in witness_inputs' order.  flag (None, or the slot's `signed` value): with a flag the statement is
     "flag = 1  =>  sig64 is the key's signature of msg" — the key and message that enter the verification are SELECTED by the flag between the
@@ -566,7 +629,7 @@ def verify_statement(b, pub32, sig64, msg, flag=None):
     Returns {"key_words": 8 big-endian 32-bit word variables of the slot's public key, "msg_bytes": the message byte variables,
     "flag": the flag variable or None, "stats": {...}}.  ValueError when the signature does not verify (some constraint fails on its witness)."""
     pub32, msg = bytes(pub32), bytes(msg)
-    vals = witness_inputs(pub32, sig64, msg, flag)
+    vals = witness_inputs(pub32, sig64, msg, flag, split_scalars=split_scalars)
     it = iter(vals)
     f = NNF(b)
     g = Sha512Gadget(b)
@@ -644,11 +707,76 @@ def verify_statement(b, pub32, sig64, msg, flag=None):
             b.assert_bool(bit)
         b.assert_equal(g.pack(lb), v)
         k_bits += lb
-    k_nibbles = [k_bits[4 * w: 4 * w + 4] for w in range(64)]
-    # [S]B = R + [k]A, compared projectively
-    Q1 = ed.mul_base(s_nibbles)
-    Q2 = ed.mul_var(PA, k_nibbles)
-    Q3 = ed.add_niels(Q2, (f.add(PR[1], PR[0]), f.sub(PR[1], PR[0]), None, f.mul(PR[3], ed.d2)), need_t=False)
+    if not split_scalars:
+        # [S]B = R + [k]A, compared projectively
+        k_nibbles = [k_bits[4 * w: 4 * w + 4] for w in range(64)]
+        Q1 = ed.mul_base(s_nibbles)
+        Q2 = ed.mul_var(PA, k_nibbles)
+        Q3 = ed.add_niels(Q2, (f.add(PR[1], PR[0]), f.sub(PR[1], PR[0]), None, f.mul(PR[3], ed.d2)), need_t=False)
+    else:
+        # The same equation with HALF-SIZE scalars (half_size_pair): for an odd u and a v below 2^144 with u k = +-v (mod L),
+        #     [S]B = R + [k]A   <=>   [u S mod L]B = [u]R + [v](+-A)
+        # (multiply by u: it is odd and invertible mod L, so nothing of order 8 or L is lost).  The two 144-bit scalars share ONE doubling chain:
+        # 140 doublings and 72 additions instead of 252 and 64 — about 620 field products fewer per signature.
+        def small(n_limbs, n_bits):
+            vs = [b.var(next(it)) for _ in range(n_limbs)]
+            bits = []
+            for i, v in enumerate(vs):
+                lb = [b.bit(v, j) for j in range(min(LB, n_bits - LB * i))]
+                for bit in lb:
+                    b.assert_bool(bit)
+                b.assert_equal(g.pack(lb), v)                                      # the bits ARE the limb (so it is tight, and the top ones absent)
+                bits += lb
+            return vs, bits
+        u_l, u_bits = small(6, 4 * HALF_NIBBLES)
+        v_l, v_bits = small(6, 4 * HALF_NIBBLES)
+        b.assert_equal(u_bits[0], f.one)                                           # u is odd (hence non-zero)
+        neg = b.var(next(it))
+        b.assert_bool(neg)
+        q1 = [b.range32(b.var(next(it))) for _ in range(7)]
+        w_l, w_bits = small(NL, 256)
+        q2 = [b.range32(b.var(next(it))) for _ in range(7)]
+        sgn = b.arith(P - 2, 0, 1, neg, f.one, neg)                                 # +1 or -1
+        ell_l = limbs_of(ELL)
+
+        def relation(prod_a, prod_b, quot, tail, tail_coef):
+            """sum_{i+j=t} a_i b_j - sum quot_i L_j - tail_coef * tail_t = 0 over the integers, column by column with signed carries"""
+            carry = None
+            n_cols = max(len(prod_a) + len(prod_b), len(quot) + NL) + 1
+            for col in range(n_cols):
+                acc = None
+                for i, x in enumerate(prod_a):
+                    j = col - i
+                    if 0 <= j < len(prod_b):
+                        acc = b.arith(1, 0, 0, x, prod_b[j], x) if acc is None else b.arith(1, 1, 0, x, prod_b[j], acc)
+                for i, x in enumerate(quot):
+                    j = col - i
+                    if 0 <= j < NL and ell_l[j]:
+                        acc = b.arith(P - ell_l[j], 0, 0, x, f.one, x) if acc is None else b.arith(P - ell_l[j], 1, 0, x, f.one, acc)
+                if col < len(tail):
+                    t = b.arith(P - 1, 0, 0, tail[col], tail_coef, tail[col])
+                    acc = t if acc is None else b.arith(1, 1, 0, t, f.one, acc)
+                if carry is not None:
+                    acc = carry if acc is None else b.arith(1, 1, 0, carry, f.one, acc)
+                if acc is None:
+                    continue
+                if col < n_cols - 1:
+                    shifted = b.arith(1, 0, 1 << 54, acc, f.one, acc)               # |acc| < 2^53: acc + 2^54 is positive, its bits above 24 = carry + 2^30
+                    cs = b.bit_field(shifted, LB, 32)
+                    b.range32(cs)
+                    carry = b.arith(1, 0, P - (1 << 30), cs, f.one, cs)
+                    b.assert_equal(b.arith(1 << LB, 0, 0, carry, f.one, carry), acc)
+                else:
+                    b.assert_equal(acc, f.zero)
+        relation(u_l, s_limbs, q1, w_l, f.one)                                      # u S = q1 L + w
+        relation(u_l, k_s.limbs, q2, v_l, sgn)                                      # u k = q2 L +- v
+        nib = lambda bits, n: [bits[4 * i: 4 * i + 4] for i in range(n)]
+        Q1 = ed.mul_base(nib(w_bits, 64))
+        # +-A: the x coordinate (and T = x y) negated when neg = 1
+        nx = f.lincomb([], [PA[0]])
+        ax = Fq([b.arith(1, 1, 0, neg, b.arith(1, P - 1, 0, m, f.one, x), x) for x, m in zip(PA[0].limbs, nx.limbs)], max(PA[0].bound, nx.bound))
+        As = (ax, PA[1], PA[2], f.mul(ax, PA[1]))
+        Q3 = ed.mul_var2(PR, nib(u_bits, HALF_NIBBLES), As, nib(v_bits, HALF_NIBBLES))
     f.assert_equal(f.mul(Q1[0], Q3[2]), f.mul(Q3[0], Q1[2]))
     f.assert_equal(f.mul(Q1[1], Q3[2]), f.mul(Q3[1], Q1[2]))
     key_words = []
@@ -663,7 +791,7 @@ def ed25519_circuit(prover, pub32, sig64, msg):
     """the circuit of verify_statement: public inputs = the 8 key words then the message bytes.  Returns (builder, statement dict)."""
     from . import SHA_GATE_WIRES
     from .recursion import CircuitBuilder
-    b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES)
+    b = CircuitBuilder(prover, n_wires=SHA_GATE_WIRES, n_routed=SHA_GATE_WIRES)        # every wire routed: 36 gate slots per row
     st = verify_statement(b, pub32, sig64, msg)
     for v in st["key_words"] + st["msg_bytes"]:
         b.public_input(v)

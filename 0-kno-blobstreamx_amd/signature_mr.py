@@ -3,7 +3,8 @@ upstream names recalled, unverified — reference file:line NONE, the mount is e
 accelerator).
 
 Map      one leaf per validator SLOT of the target set: "flag = 1  =>  the slot's key signed these vote bytes" (ed25519_circuit.verify_statement
-         with a flag: about 2 950 non-native field products, 92k rows of a 2^17-row circuit; a slot with flag 0 verifies a fixed dummy triple).
+         with a flag, half-size scalars, all 144 wires routed: 2 312 non-native field products, 61.6k rows of a 2^16-row circuit; a slot with flag 0
+         verifies a fixed dummy triple).
          Public inputs: the key's 8 big-endian words, the flag, and the 8 words of the BLOCK HASH the vote bytes carry at `hash_offset`.
 Reduce   a node verifies `fan_in` children in-circuit, requires that all of them vote for the same block hash, and folds their signer-digest
          leaves (gadgets.signer_leaf: Poseidon over key words and flag) into the binary Poseidon tree gadgets._signer_digest defines.
@@ -43,6 +44,9 @@ class SignatureSetMapReduce(DataCommitmentMapReduce):
     def _child_has_poseidon_rows(self, level):
         return level > 1                             # a signature leaf is arithmetic gates and ADD rows only
 
+    def _child_n_routed(self, level):
+        return 144 if level == 1 else 80             # the signature leaf routes all 144 wires (36 gate slots per row): 61.6k rows, a 2^16-row circuit
+
     def _child_has_sha_rows(self, level):
         return level == 1                            # ... and the nodes above have Poseidon rows and arithmetic only
 
@@ -73,7 +77,7 @@ class SignatureSetMapReduce(DataCommitmentMapReduce):
         t0 = time.perf_counter()
         msg = self.vote_bytes(bytes(32))
         pub, sig = keypair_and_sign(bytes(32), msg)
-        b = CircuitBuilder(self.prover, n_wires=SHA_GATE_WIRES)
+        b = CircuitBuilder(self.prover, n_wires=SHA_GATE_WIRES, n_routed=SHA_GATE_WIRES)
         st = verify_statement(b, pub, sig, msg, flag=True)
         one = b.constant(1)
         hb = st["msg_bytes"][self.hash_offset:self.hash_offset + 32]
