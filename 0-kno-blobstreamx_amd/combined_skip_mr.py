@@ -116,6 +116,10 @@ class CombinedSkipMapReduce:
                 "target_block": public[21], "commitment": be(public[22:30]), "outer_rows": rp.stats["rows"]}
 
     # ---- proving ----------------------------------------------------------------------------------------------------------------------
+    def _disjoint_provers(self):
+        mine = {id(p) for p in [self.chain.prover] + list(self.chain.map_provers)}
+        return self.sigs is not None and not (mine & {id(p) for p in [self.sigs.prover] + list(self.sigs.map_provers)})
+
     def _prove_votes(self, target, signed, votes, chain_headers, distributed=None):
         if votes is None:
             return None
@@ -133,12 +137,25 @@ class CombinedSkipMapReduce:
         validators' flags; trusted_index[i] = position of target validator i in the trusted set, or None.  ValueError when a premise fails."""
         self._check_shapes(trusted_fields, chain_headers, trusted_height)
         start = HeaderChainMapReduce.header_hash(trusted_fields)
-        t0 = time.perf_counter()
-        out = self.chain.prove_chain(start, trusted_height + 1, chain_headers)
-        t_chain = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        sig_out = self._prove_votes(target, signed, votes, chain_headers)
-        t_sig = time.perf_counter() - t0
+
+        def chain_part():
+            t0 = time.perf_counter()
+            o = self.chain.prove_chain(start, trusted_height + 1, chain_headers)
+            return o, time.perf_counter() - t0
+
+        def vote_part():
+            t0 = time.perf_counter()
+            o = self._prove_votes(target, signed, votes, chain_headers)
+            return o, time.perf_counter() - t0
+        if votes is not None and self._disjoint_provers():
+            # the two MapReduces have provers (ctxs) of their own: run them side by side — the latency-bound tails of one Reduce (a few node
+            # proofs, then one root) overlap the throughput-bound Map of the other
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(2) as ex:
+                fc, fv = ex.submit(chain_part), ex.submit(vote_part)
+                (out, t_chain), (sig_out, t_sig) = fc.result(), fv.result()
+        else:
+            (out, t_chain), (sig_out, t_sig) = chain_part(), vote_part()
         res = self._finish(out["root_proof"], out["key"], out["leaves"] > 1, (trusted_fields, trusted, chain_headers, target, signed, trusted_index,
                                                                                trusted_height), t_chain, sig_out)
         res.update(leaves=out["leaves"], map_seconds=out["map_seconds"], reduce_seconds=out["reduce_seconds"], levels=out["levels"],
@@ -153,6 +170,13 @@ class CombinedSkipMapReduce:
         """prove_skip with the chain spread over the ranks (HeaderChainMapReduce.prove_chain_distributed); the outer circuit is proved on rank 0.
         Every rank passes the whole case.  Returns the prove_skip dict on rank 0, {"root_proof": None, ...} elsewhere."""
         self._check_shapes(trusted_fields, chain_headers, trusted_height)
+        mrm = importlib.import_module(__package__ + ".mapreduce")
+        if mrm._world(comm)[1] == 1:
+            # one rank: no exchange to order — the plain form, which may run the two MapReduces side by side (at N > 1 they stay sequential: their
+            # collectives must be entered in the same order on every rank)
+            res = self.prove_skip(trusted_fields, trusted, chain_headers, target, signed, trusted_index, trusted_height, votes=votes)
+            res["ranks"] = 1
+            return res
         start = HeaderChainMapReduce.header_hash(trusted_fields)
         t0 = time.perf_counter()
         out = self.chain.prove_chain_distributed(start, trusted_height + 1, chain_headers, device=device, comm=comm)

@@ -922,7 +922,11 @@ def combined_skip_leg(pkg, rank, local_rank, world, skips=(128, 1024), n_validat
     sig_leaves = sig_skip // 8
     if os.environ.get("GLP_BENCH_SIGNATURES", "1") != "0" and sig_leaves % world == 0 and 128 % world == 0 and 128 // world >= 2:
         sm = importlib.import_module(graft.PKG_NAME + ".signature_mr")
-        sigs = sm.SignatureSetMapReduce(provers[0], consts, msg_len=112, hash_offset=16, fan_in=8, map_provers=provers[1:])
+        # the signature MapReduce gets three provers (ctxs) of its own: at N = 1 the chain and the signatures are then proved side by side
+        sig_provers = [pkg.Prover(_gpu_index(local_rank)) for _ in range(3)]
+        for p in sig_provers:
+            p.set_poseidon_constants(*consts)
+        sigs = sm.SignatureSetMapReduce(sig_provers[0], consts, msg_len=112, hash_offset=16, fan_in=8, map_provers=sig_provers[1:])
         mr = cs.CombinedSkipMapReduce(provers[0], consts, skip=sig_skip, chain=chain, max_skip=4096, signatures=sigs)
         entry = {"headers": sig_skip, "chain_leaves": sig_leaves, "validators": n_validators, "signature_slots": 128, "vote_bytes": 112}
         for run in ("first_run_records_circuits", "steady_state"):
@@ -995,6 +999,8 @@ def combined_skip_leg(pkg, rank, local_rank, world, skips=(128, 1024), n_validat
             res[f"skip_{sig_skip}_with_signatures"] = entry
         mr.free()
         sigs.free()
+        for p in sig_provers:
+            p.close()
     if rank == 0:
         res["leaf"] = {k: v for k, v in chain.leaf_program.stats.items() if k in ("rows", "rows_used", "sha_rows")}
         res["note"] = ("build-defined statement (NOT upstream's circuit): public inputs of the final proof = trusted header hash, target header hash, "
