@@ -15,7 +15,7 @@ inside the one proof system with the gates it already has — no new row kinds, 
   * ``verify_statement``  RFC 8032 §5.1.7 with the cofactorless equation [S]B = R + [k]A: canonical decoding of A and R (the x coordinates are
                  witnesses checked against the curve equation and the sign bit), S < L, k = SHA-512(R || A || M) mod L (quotient witnessed,
                  k < L), the two scalar multiplications, projective comparison.  A signature that does not verify cannot be laid down.
-One signature = about 2 950 field products, ~95k rows of 144 wires: a 2^17-row circuit (measured: bench leg ``ed25519_circuit``).
+One signature = 2 312 field products (half-size scalars), 61.6k rows of 144 routed wires: a 2^16-row circuit (bench leg ``combined_skip``).
 Everything here is build-defined (NOT curta's AIR); formats are RFC 8032 / FIPS 180-4 restated from memory and pinned by the RFC 8032 §7.1
 vectors and OpenSSL-made fixtures (tests/golden/ed25519.json) and hashlib."""
 import hashlib
