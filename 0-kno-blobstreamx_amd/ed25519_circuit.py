@@ -540,13 +540,15 @@ HALF_NIBBLES = 36                     # windows of the half-size scalars: 144 bi
 
 
 def half_size_pair(k):
-    """(u, v, neg): u ODD, 0 < u, 0 <= v, both below 2^144, with  u * k = (-v if neg else v)  (mod L).  A short vector of the lattice
-    {(t, r): r = t k mod L} (determinant L ~ 2^252.4) by Lagrange reduction; among the reduced basis and its sum one vector has an odd first
-    coordinate (the lattice contains (1, k)).  With them  [S]B = R + [k]A  <=>  [u S]B = [u]R + [+-v]A  — two 144-bit scalars on ONE shared doubling
-    chain instead of a 253-bit one (u odd and prime-order-invertible: no small-order slack is introduced).  ValueError in the ~2^-36 case that no
-    such pair fits 144 bits."""
+    """(u, v, neg): u ODD, 0 < u, 0 <= v, both below 2^144, with  u * k = (-v if neg else v)  (mod 8 L).  A short vector of the lattice
+    {(t, r): r = t k mod 8L} (determinant 8L ~ 2^255.4) by Lagrange reduction; among the reduced basis and its sum / difference one vector has an
+    odd first coordinate (the lattice contains (1, k)).  With them  [S]B = R + [k]A  <=>  [u S]B = [u]R + [+-v]A  — two 144-bit scalars on ONE shared
+    doubling chain instead of a 253-bit one.  The modulus is the GROUP EXPONENT 8L, not L: [u k]A = [+-v]A then holds for EVERY curve point A, also
+    one with a small-order component (a mod-L relation would be off by [q L]A, a point of order up to 8, for such keys); and u is odd and below L,
+    so [u]X = O forces X = O: the split form is EXACTLY the cofactorless equation of RFC 8032, not an up-to-torsion variant.  ValueError in the
+    ~2^-36 case that no such pair fits 144 bits."""
     k %= ELL
-    b1, b2 = (1, k), (0, ELL)
+    b1, b2 = (1, k), (0, 8 * ELL)
     norm = lambda v: v[0] * v[0] + v[1] * v[1]
     if norm(b1) > norm(b2):
         b1, b2 = b2, b1
@@ -563,7 +565,7 @@ def half_size_pair(k):
     u, neg = abs(t), t < 0
     if u >> (4 * HALF_NIBBLES) or r >> (4 * HALF_NIBBLES):
         raise ValueError("no half-size scalar pair below 2^144 for this signature (probability ~2^-36)")
-    assert (u * k - (-r if neg else r)) % ELL == 0 and u & 1
+    assert (u * k - (-r if neg else r)) % (8 * ELL) == 0 and u & 1 and u < ELL
     return u, r, neg
 
 
@@ -613,11 +615,11 @@ def witness_inputs(pub32, sig64, msg, flag=None, record=None, split_scalars=True
     out = head + body + limbs_of(xa) + limbs_of(xr) + limbs_of(t) + limbs_of(k)
     if not split_scalars:
         return out
-    # the half-size form: u, v, the sign, and the quotients / remainder of  u * S = q1 * L + w  and  u * k -+ v = q2 * L
+    # the half-size form: u, v, the sign, and the quotients / remainder of  u * S = q1 * L + w  and  u * k -+ v = q2 * 8L
     S = int.from_bytes(sig64[32:], "little")
     u, v, neg = half_size_pair(k)
     q1, w = divmod(u * S, ELL)
-    q2 = (u * k - (-v if neg else v)) // ELL
+    q2 = (u * k - (-v if neg else v)) // (8 * ELL)
     return out + limbs_of(u, 6) + limbs_of(v, 6) + [1 if neg else 0] + limbs_of(q1, 7) + limbs_of(w) + limbs_of(q2, 7)
 
 
@@ -714,9 +716,9 @@ def verify_statement(b, pub32, sig64, msg, flag=None, split_scalars=True):
         Q2 = ed.mul_var(PA, k_nibbles)
         Q3 = ed.add_niels(Q2, (f.add(PR[1], PR[0]), f.sub(PR[1], PR[0]), None, f.mul(PR[3], ed.d2)), need_t=False)
     else:
-        # The same equation with HALF-SIZE scalars (half_size_pair): for an odd u and a v below 2^144 with u k = +-v (mod L),
+        # The same equation with HALF-SIZE scalars (half_size_pair): for an odd u and a v below 2^144 with u k = +-v (mod 8L),
         #     [S]B = R + [k]A   <=>   [u S mod L]B = [u]R + [v](+-A)
-        # (multiply by u: it is odd and invertible mod L, so nothing of order 8 or L is lost).  The two 144-bit scalars share ONE doubling chain:
+        # (multiply by u: it is odd and invertible mod L, so nothing of order 8 or L is lost; 8L is the group exponent, so [u k]A = [+-v]A for every A).  The two 144-bit scalars share ONE doubling chain:
         # 140 doublings and 72 additions instead of 252 and 64 — about 620 field products fewer per signature.
         def small(n_limbs, n_bits):
             vs = [b.var(next(it)) for _ in range(n_limbs)]
@@ -737,10 +739,10 @@ def verify_statement(b, pub32, sig64, msg, flag=None, split_scalars=True):
         w_l, w_bits = small(NL, 256)
         q2 = [b.range32(b.var(next(it))) for _ in range(7)]
         sgn = b.arith(P - 2, 0, 1, neg, f.one, neg)                                 # +1 or -1
-        ell_l = limbs_of(ELL)
-
-        def relation(prod_a, prod_b, quot, tail, tail_coef):
-            """sum_{i+j=t} a_i b_j - sum quot_i L_j - tail_coef * tail_t = 0 over the integers, column by column with signed carries"""
+        def relation(prod_a, prod_b, quot, tail, tail_coef, modulus):
+            """sum_{i+j=t} a_i b_j - sum quot_i M_j - tail_coef * tail_t = 0 over the integers (M = the modulus' limbs), column by column with
+            signed carries"""
+            ell_l = limbs_of(modulus)
             carry = None
             n_cols = max(len(prod_a) + len(prod_b), len(quot) + NL) + 1
             for col in range(n_cols):
@@ -768,8 +770,8 @@ def verify_statement(b, pub32, sig64, msg, flag=None, split_scalars=True):
                     b.assert_equal(b.arith(1 << LB, 0, 0, carry, f.one, carry), acc)
                 else:
                     b.assert_equal(acc, f.zero)
-        relation(u_l, s_limbs, q1, w_l, f.one)                                      # u S = q1 L + w
-        relation(u_l, k_s.limbs, q2, v_l, sgn)                                      # u k = q2 L +- v
+        relation(u_l, s_limbs, q1, w_l, f.one, ELL)                                 # u S = q1 L + w           (B has order exactly L)
+        relation(u_l, k_s.limbs, q2, v_l, sgn, 8 * ELL)                             # u k = q2 8L +- v          (8L kills every curve point)
         nib = lambda bits, n: [bits[4 * i: 4 * i + 4] for i in range(n)]
         Q1 = ed.mul_base(nib(w_bits, 64))
         # +-A: the x coordinate (and T = x y) negated when neg = 1

@@ -131,9 +131,9 @@ def test_half_size_scalar_pairs():
     rng = random.Random(12)
     for k in [0, 1, 2, ec.ELL - 1, ec.ELL - 2, 1 << 126, (1 << 252) + 5] + [rng.randrange(ec.ELL) for _ in range(300)]:
         u, v, neg = ec.half_size_pair(k)
-        assert u & 1 and 0 < u < 1 << 140 and 0 <= v < 1 << 140 and (u * k - (-v if neg else v)) % ec.ELL == 0
+        assert u & 1 and 0 < u < 1 << 140 and 0 <= v < 1 << 140 and (u * k - (-v if neg else v)) % (8 * ec.ELL) == 0
     with pytest.raises(ValueError):
-        # k = 1/2 mod L: the lattice's short vector is (2, 1) — EVEN — and every odd one is ~2^251 long.  Such k (probability ~2^-36 even when
+        # k = 1/2 mod L: 2 k = L + 1, the lattice's short vectors all have an EVEN first coordinate ((8, 4 + 4 L mod 8L) ...) and every odd one is huge.  Such k (probability ~2^-36 even when
         # ground for; a validator who grinds its nonce for one only makes its own signature unprovable: its slot is then flagged 0) have no
         # split form; split_scalars=False remains for them
         ec.half_size_pair((ec.ELL + 1) // 2)
