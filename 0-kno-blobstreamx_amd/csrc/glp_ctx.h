@@ -20,6 +20,8 @@ struct glp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;        // own_stream or an adopted one
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipStream_t aux_stream = nullptr;    // second stream of large NTT batches (glp_ntt_impl), forked from / joined into `stream` by the two events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t pass_ev[2 * GLP_MAX_PASSES] = {};
     int profiling = 0;
     int last_npass = 0;

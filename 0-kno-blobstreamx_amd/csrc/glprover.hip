@@ -212,6 +212,8 @@ struct HipBackend {
     glp_ctx* c;
     int rc = GLP_OK;
     int npass = 0;
+    hipStream_t st = nullptr;            // launch stream (the ctx's stream unless set)
+    hipStream_t stream() const { return st ? st : c->stream; }
     const u64* table_lo(int log_N, int inv) {
         if (ensure_table(c, log_N, inv) != GLP_OK) { rc = GLP_E_HIP; return nullptr; }
         return c->tables[log_N * 2 + (inv ? 1 : 0)].lo;
@@ -269,7 +271,7 @@ struct HipBackend {
         if (rc != GLP_OK) return rc;
         if (lds > 160 * 1024 || block > 1024 || block < 64) { glp_set_err(c, "bad launch geometry"); return GLP_E_INVALID; }
         mark(2 * npass);
-        hipError_t e = glp_launch_ntt_pass(ps.log_r, ps.mode, inv, ps.log_e, (unsigned)grid, block, lds, c->stream, &a);
+        hipError_t e = glp_launch_ntt_pass(ps.log_r, ps.mode, inv, ps.log_e, (unsigned)grid, block, lds, stream(), &a);
         mark(2 * npass + 1);
         npass++;
         if (e != hipSuccess) { glp_set_err(c, "ntt pass launch: %s", hipGetErrorString(e)); return GLP_E_HIP; }
@@ -364,6 +366,7 @@ extern "C" void glp_destroy(glp_ctx* c) {
     hipEventDestroy(c->t0);
     hipEventDestroy(c->t1);
     for (int i = 0; i < 2 * GLP_MAX_PASSES; i++) hipEventDestroy(c->pass_ev[i]);
+    if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
     hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -540,6 +543,34 @@ int glp_ntt_impl(glp_ctx* c, const uint64_t* src, uint64_t* dst, uint32_t log_n,
         if (rc != GLP_OK) return rc;
     }
     HipBackend be{c};
+    // Two halves on two streams (round 3): a pass kernel's tail — the last wave of workgroups draining while the dependent next pass cannot
+    // start — and the launch gap cost ~7 % of a two-pass transform of a large batch (20-step mean 1.155 ms vs 1.067 ms of kernel time).  The
+    // polynomials are independent, so the batch is cut in two: the second half runs the same passes on an auxiliary stream (forked from and
+    // joined back into the ctx's stream by events: the call stays stream-ordered for the caller) and each half's tails and gaps are covered by
+    // the other's kernels.  MEASURED (same-box A/B, three alternations at 128 x 2^20: profiles/r03_ab_ntt_two_streams.txt): 1.108 ms without,
+    // 1.119 ms with — no gain: the difference between a transform's wall time and its kernels' isolated times is not idle tail (the chip runs
+    // isolated kernels at a higher clock than a sustained stream of them).  Kept as an OPT-IN experiment (GLP_NTT_SPLIT=1), off by default.
+    if (pl.npass >= 2 && pl.needs_scratch && chunk == batch && batch >= 2 && !c->profiling && ((u64)batch << log_n) >= (1ull << 26) &&
+        getenv("GLP_NTT_SPLIT") && atoi(getenv("GLP_NTT_SPLIT"))) {
+        if (!c->aux_stream) {
+            if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { glp_set_err(c, "glp_ntt: auxiliary stream"); return GLP_E_HIP; }
+        }
+        const u32 h = batch / 2;
+        GLP_HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        GLP_HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        GlpNttCall a{src, dst, c->scratch, ss, ds, h, (int)log_n, inv, rev};
+        GlpNttCall b{src + (u64)h * ss, dst + (u64)h * ds, c->scratch + (u64)h * n, ss, ds, batch - h, (int)log_n, inv, rev};
+        int rc = glp_exec_ntt(be, &pl, a);                    // (also makes the tables resident, on the ctx's stream, before the fork is consumed)
+        HipBackend be2{c};
+        be2.st = c->aux_stream;
+        if (rc == GLP_OK) rc = glp_exec_ntt(be2, &pl, b);
+        GLP_HIPCHK(c, hipEventRecord(c->ev_join, c->aux_stream));
+        GLP_HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        if (rc != GLP_OK) { if (rc > -10 && c->err[0] == 0) glp_set_err(c, "glp_ntt: exec rc=%d", rc); return rc < -6 ? GLP_E_INVALID : rc; }
+        c->last_npass = be.npass;
+        return GLP_OK;
+    }
     for (u32 b0 = 0; b0 < batch; b0 += chunk) {
         const u32 nb = (batch - b0 < chunk) ? batch - b0 : chunk;
         GlpNttCall call{src + (u64)b0 * ss, dst + (u64)b0 * ds, c->scratch, ss, ds, nb, (int)log_n, inv, rev};

@@ -98,6 +98,12 @@ int glp_exec_ntt(Backend& be, const GlpPlan* pl, const GlpNttCall& c) {
             const u32 g = 4u - (u32)ps.log_c;
             if (grid % (8ull << g) == 0) a.xcd_group_log = g;
         }
+        // FINAL_T tiles narrower than a line WRITE half (quarter ...) lines: the same pairing puts the tiles that complete each other's lines on one
+        // XCD (same-box A/B at 128 x 2^20, three alternations: FINAL_T pass 0.494-0.509 -> 0.459-0.482 ms; GLP_FINALT_XCD=0 switches it off)
+        if (ps.mode == GLP_FINAL_T && ps.log_c < 4 && !(getenv("GLP_FINALT_XCD") && !atoi(getenv("GLP_FINALT_XCD")))) {
+            const u32 g = 4u - (u32)ps.log_c;
+            if (grid % (8ull << g) == 0) a.xcd_group_log = g;
+        }
         a.poly_minor = (ps.mode == GLP_STRIP && a.tw_full && c.batch > 1) ? 1u : 0u;
         if (a.poly_minor && a.xcd_group_log) {
             // the pairing of line-sharing strips must survive the (position, polynomial) order:

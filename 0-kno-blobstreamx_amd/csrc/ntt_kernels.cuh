@@ -181,7 +181,9 @@ __global__ void __launch_bounds__((GlpBounds<LOG_E, MODE, CT_LOG_C>::threads), (
     const u32 tid = threadIdx.x;
     const u32 ldA = C + 1;                   // layout A: [row][C+1]
     u64 tile = blockIdx.x;
-    if constexpr (MODE == GLP_STRIP) {
+    if constexpr (MODE == GLP_STRIP || MODE == GLP_FINAL_T) {
+        // (FINAL_T, round 3: its tiles WRITE C * 8-byte segments, so tiles t and t + 1 write the two halves of the same 128-B lines; on the same
+        // XCD the halves can merge in its L2 before they leave for HBM)
         // Strips narrower than a 128-B line share lines with their neighbours.  Workgroups b and
         // b+8 are observed to land on the same XCD (private L2), so give the 2^g line-sharing
         // strips the ids b, b+8, ...: the second toucher then hits in L2 instead of HBM.
