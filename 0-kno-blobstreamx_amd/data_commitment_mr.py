@@ -183,10 +183,12 @@ class DataCommitmentMapReduce:
             self.record_seconds[f"node_level{level}_fan{len(proofs)}"] = round(time.perf_counter() - t0, 3)
         return self.nodes[k]
 
-    def reduce(self, proofs, timings=None, child_key=None, level=1, span=None):
+    def reduce(self, proofs, timings=None, child_key=None, level=1, span=None, max_levels=None):
         """fold child proofs level by level; returns (root proof, its public inputs, its verifying key, the next level number).  child_key /
         level / span: where the fold starts (default: leaf proofs at level 1, each covering leaf_blocks units; a later start folds node proofs made
-        elsewhere, e.g. on other ranks, each covering `span` units)"""
+        elsewhere, e.g. on other ranks, each covering `span` units).  max_levels: stop after that many levels and return the LIST of node proofs
+        of the last one in place of the root"""
+        levels_done = 0
         cur, key, public = list(proofs), (self.leaf_circuit.cap() if child_key is None else child_key), None
         span = self.leaf_blocks if span is None else span
         while True:
@@ -219,6 +221,10 @@ class DataCommitmentMapReduce:
                 timings.append({"level": level, "nodes": len(nxt), "fan_in": fan, "rows": rp.stats["rows"],
                                 "seconds_including_first_recording": round(time.perf_counter() - t0, 4)})
             key, level, span = rp.key(), level + 1, span * fan
+            levels_done += 1
+            if max_levels is not None and levels_done >= max_levels:
+                self.last_span = span
+                return nxt, public, key, level
             if len(nxt) == 1:
                 self.last_span = span
                 return nxt[0], public, key, level

@@ -105,11 +105,11 @@ class SignatureSetMapReduce(DataCommitmentMapReduce):
         dw, public = self.leaf_program.device_witness(prover, vals, reuse=True)
         return circuit.prove_(dw, self.nq, self.pw, public=public), public
 
-    def _slots(self, pubkeys, signatures, msgs, flags):
+    def _slots(self, pubkeys, signatures, msgs, flags, total=None):
         n = len(pubkeys)
         if not (len(signatures) == len(msgs) == len(flags) == n) or n < 1:
             raise ValueError("one signature (or None), vote and flag per validator")
-        total = 1 << max(0, (n - 1).bit_length())
+        total = (1 << max(0, (n - 1).bit_length())) if total is None else total
         pad = total - n
         return (list(pubkeys) + [bytes(32)] * pad, list(signatures) + [None] * pad, list(msgs) + [msgs[0]] * pad, [bool(f) for f in flags] + [False] * pad)
 
@@ -137,18 +137,57 @@ class SignatureSetMapReduce(DataCommitmentMapReduce):
         flags[i] is false.  ValueError when a flagged slot's signature does not verify or the votes name different blocks."""
         if self.leaf_program is None:
             self._record_leaf()
-        slots = self._slots(pubkeys, signatures, msgs, flags)
+        n, F = len(pubkeys), self.fan_in
+        groups, full = -(-n // F), 1 << max(0, (n - 1).bit_length())
+        # Padding to a power of two can cost a lot of whole leaves (100 validators -> 128 slots: 28 dummy verifications).  When the level-1
+        # groups fit ONE root (<= 16), only the last group is padded and the root takes the real groups' node proofs plus CONSTANT digests for
+        # the all-padding groups: the signer digest is the same 128-slot tree, 24 leaves and 3 nodes are never proved.
+        trimmed = groups * F < full and 2 <= groups <= 16 and full % F == 0 and n > F
+        slots = self._slots(pubkeys, signatures, msgs, flags, total=groups * F if trimmed else None)
         t0 = time.perf_counter()
         leaves = self._map(slots, 0, len(slots[0]))
         t1 = time.perf_counter()
         levels = []
         if len(leaves) == 1:
             raise ValueError("a set of one slot has no node to fold it: use at least two validators")
-        root, public, key, _ = self.reduce(leaves, levels)
+        if trimmed:
+            nodes, _, key1, lvl = self.reduce(leaves, levels, max_levels=1)
+            root, public, key = self._padded_root(nodes, key1, lvl, full // F, levels)
+        else:
+            root, public, key, _ = self.reduce(leaves, levels)
         t2 = time.perf_counter()
         return {"root_proof": root, "public": public, "key": key, "slots": len(leaves), "map_seconds": round(t1 - t0, 4),
                 "reduce_seconds": round(t2 - t1, 4), "levels": levels, "record_seconds": dict(self.record_seconds),
                 "block_hash": b"".join(struct.pack(">I", v) for v in public[:8]), "signer_digest": public[8:12]}
+
+    def _padded_root(self, nodes, child_key, level, total_groups, timings=None):
+        """ONE root over len(nodes) level-1 node proofs and (total_groups - len(nodes)) all-padding groups, whose subtree digest is a constant of
+        the circuit (computed in it from the padding leaf): the same statement and digest as the power-of-two tree"""
+        vc = importlib.import_module(__package__ + ".verifier_circuit")
+        k = ("padded_root", len(nodes), total_groups, bytes(np.ascontiguousarray(child_key, dtype=np.uint64)))
+        t0 = time.perf_counter()
+        if k not in self.nodes:
+            F = self.fan_in
+
+            def combine(b, outs):
+                hashes = [o["public"][:8] for o in outs]
+                for other in hashes[1:]:
+                    for x, y in zip(hashes[0], other):
+                        b.assert_equal(x, y)
+                zero = b.constant(0)
+                pad_group = signer_tree(b, [signer_leaf(b, [zero] * 8, zero)] * F)
+                return hashes[0] + signer_tree(b, [o["public"][8:12] for o in outs] + [pad_group] * (total_groups - len(outs)))
+            spec = dict(leaf_key=child_key, n_public=self.N_PUBLIC, child_is_recursion=True, child_sha=False)
+            self.nodes[k] = vc.RecursionProgram(self.prover, nodes, child_key, self.nq, self.pw, SHA_GATE_WIRES, self.consts, n_routed=80,
+                                                n_public=self.N_PUBLIC, cap_height=1, child_is_recursion=True, child_sha=False, combine=combine,
+                                                builder_wires=SHA_GATE_WIRES, specs=[spec] * len(nodes))
+            self.record_seconds[f"padded_root_{len(nodes)}_of_{total_groups}"] = round(time.perf_counter() - t0, 3)
+        rp = self.nodes[k]
+        proof, public = rp.prove(nodes, self.nq, self.pw)
+        if timings is not None:
+            timings.append({"level": level, "nodes": 1, "fan_in": len(nodes), "constant_groups": total_groups - len(nodes), "rows": rp.stats["rows"],
+                            "seconds_including_first_recording": round(time.perf_counter() - t0, 4)})
+        return proof, public, rp.key()
 
     def prove_set_distributed(self, pubkeys, signatures, msgs, flags, device=None, comm=None):
         """prove_set with the slots spread over the ranks: rank r proves and folds the r-th contiguous part, ONE all-gather of node proofs, rank 0

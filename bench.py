@@ -928,7 +928,7 @@ def combined_skip_leg(pkg, rank, local_rank, world, skips=(128, 1024), n_validat
             p.set_poseidon_constants(*consts)
         sigs = sm.SignatureSetMapReduce(sig_provers[0], consts, msg_len=112, hash_offset=16, fan_in=8, map_provers=sig_provers[1:])
         mr = cs.CombinedSkipMapReduce(provers[0], consts, skip=sig_skip, chain=chain, max_skip=4096, signatures=sigs)
-        entry = {"headers": sig_skip, "chain_leaves": sig_leaves, "validators": n_validators, "signature_slots": 128, "vote_bytes": 112}
+        entry = {"headers": sig_skip, "chain_leaves": sig_leaves, "validators": n_validators, "signer_digest_slots": 128, "vote_bytes": 112}
         for run in ("first_run_records_circuits", "steady_state"):
             t_gen = time.perf_counter()
             *case, seeds = mr.synthetic_case(n_validators, n_validators, idx, trusted_height=4_100_000 + (run == "steady_state"),
@@ -958,6 +958,7 @@ def combined_skip_leg(pkg, rank, local_rank, world, skips=(128, 1024), n_validat
                               "signature_map_seconds_max_over_ranks": round(smap_s, 4), "signature_seconds_rank0": out["signature_seconds"],
                               "chain_seconds_rank0": out["chain_seconds"], "outer_seconds": out["outer_seconds"], "outer_rows": out["outer_rows"],
                               "signature_levels_on_rank0": out["signature_levels"], "signers": int(sum(signed)),
+                              "signature_leaves_proved": out["signature_slots"],
                               "verified_with_the_host_signer_digest": bool(ok), "verify_seconds": round(time.perf_counter() - t1, 4),
                               "signatures_per_second": round(int(sum(signed)) / max(out["signature_seconds"], 1e-9), 1),
                               "root_proof_bytes": len(out["root_proof"]), "synthetic_keys_and_votes_python_seconds": round(t_gen, 2)}
@@ -968,7 +969,7 @@ def combined_skip_leg(pkg, rank, local_rank, world, skips=(128, 1024), n_validat
             chain1 = dm.HeaderChainMapReduce(provers[0], consts, leaf_headers=1, fan_in=8, map_provers=provers[1:])
             st = cs.CombinedSkipMapReduce(provers[0], consts, skip=1, batch=1, chain=chain1, max_skip=4096, signatures=sigs)
             ident = list(range(n_validators))
-            step = {"headers": 1, "validators": n_validators, "signature_slots": 128}
+            step = {"headers": 1, "validators": n_validators, "signer_digest_slots": 128}
             for run in ("first_run_records_circuits", "steady_state"):
                 *case, seeds = st.synthetic_case(n_validators, n_validators, ident, trusted_height=4_200_000 + (run == "steady_state"),
                                                  seed=9000 + (run == "steady_state"), real_keys=True)
@@ -984,7 +985,8 @@ def combined_skip_leg(pkg, rank, local_rank, world, skips=(128, 1024), n_validat
                                     gd.signer_digest_host(consts, vk, signed, pad_to=128), h0, h0 + 1, out["commitment"]))
                 step[run] = {"seconds": round(dt, 4), "chain_seconds": out["chain_seconds"], "signature_seconds": out["signature_seconds"],
                              "outer_seconds": out["outer_seconds"], "outer_rows": out["outer_rows"], "verified_with_the_host_signer_digest": bool(ok),
-                             "constrained_rows_total": 128 * sigs.leaf_stats["rows"] + chain1.leaf_program.stats["rows"] + out["outer_rows"]}
+                             "signature_leaves_proved": out["signature_slots"],
+                             "constrained_rows_total": out["signature_slots"] * sigs.leaf_stats["rows"] + chain1.leaf_program.stats["rows"] + out["outer_rows"]}
             step["note"] = ("CombinedStep's shape with the real statement: the target header is the trusted header's successor (block numbers, last_block_id "
                             "link, data commitment of the one block), ONE validator set behind both headers (every target validator is the trusted "
                             "validator at its position), > 2/3 flagged, every flagged signature verified in-circuit; build-defined, NOT upstream's circuit")
