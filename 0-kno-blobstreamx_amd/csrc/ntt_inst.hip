@@ -63,7 +63,37 @@ static hipError_t launch_mode(int mode, int inv, unsigned grid, unsigned block, 
     return hipErrorInvalidValue;
 }
 
-#if defined(GLP_INST_E5)
+#if defined(GLP_INST_E6)
+// radix-64 work-items (2^11 / 2^12 tiles in two register steps): PLAIN forms with a compile-time tile width only — 128 VGPRs of data leave no
+// room for the optional features' address arithmetic or for one LDS address register per element
+template <int MODE, bool INV, int CTC>
+static hipError_t launch_e6(unsigned grid, unsigned block, size_t lds, hipStream_t st, const GlpNttPassArgs& a) {
+    auto kern = glp_ntt_pass_kernel<GLP_INST_LOG_R, MODE, INV, 6, true, CTC>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, st, a);
+    return hipGetLastError();
+}
+extern "C" hipError_t GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _e6)(int mode, int inv, unsigned grid, unsigned block, size_t lds,
+                                                                                hipStream_t st, const GlpNttPassArgs* a) {
+    if (!glp_ntt_args_plain(*a) || (a->log_c != 2 && a->log_c != 3)) return hipErrorInvalidValue;
+    switch ((mode * 2 + (inv ? 1 : 0)) * 2 + (int)(a->log_c - 2)) {
+        case (GLP_STRIP * 2 + 0) * 2 + 0: return launch_e6<GLP_STRIP, false, 2>(grid, block, lds, st, *a);
+        case (GLP_STRIP * 2 + 0) * 2 + 1: return launch_e6<GLP_STRIP, false, 3>(grid, block, lds, st, *a);
+        case (GLP_STRIP * 2 + 1) * 2 + 0: return launch_e6<GLP_STRIP, true, 2>(grid, block, lds, st, *a);
+        case (GLP_STRIP * 2 + 1) * 2 + 1: return launch_e6<GLP_STRIP, true, 3>(grid, block, lds, st, *a);
+        case (GLP_FINAL_T * 2 + 0) * 2 + 0: return launch_e6<GLP_FINAL_T, false, 2>(grid, block, lds, st, *a);
+        case (GLP_FINAL_T * 2 + 0) * 2 + 1: return launch_e6<GLP_FINAL_T, false, 3>(grid, block, lds, st, *a);
+        case (GLP_FINAL_T * 2 + 1) * 2 + 0: return launch_e6<GLP_FINAL_T, true, 2>(grid, block, lds, st, *a);
+        case (GLP_FINAL_T * 2 + 1) * 2 + 1: return launch_e6<GLP_FINAL_T, true, 3>(grid, block, lds, st, *a);
+    }
+    return hipErrorInvalidValue;
+}
+#elif defined(GLP_INST_E5)
 // the radix-32 work-items (32 elements each, split LDS exchange) are a translation unit of their own: they are compiled with the default
 // scheduler (max-ILP interleaving costs them registers they do not have: 128 VGPRs at four waves per SIMD) — csrc/Makefile
 extern "C" hipError_t GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _e5)(int mode, int inv, unsigned grid, unsigned block, size_t lds,
@@ -75,11 +105,18 @@ extern "C" hipError_t GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _
 extern "C" hipError_t GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _e5)(int mode, int inv, unsigned grid, unsigned block, size_t lds,
                                                                                 hipStream_t st, const GlpNttPassArgs* a);
 #endif
+#if GLP_INST_LOG_R >= 11
+extern "C" hipError_t GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _e6)(int mode, int inv, unsigned grid, unsigned block, size_t lds,
+                                                                                hipStream_t st, const GlpNttPassArgs* a);
+#endif
 extern "C" hipError_t GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R)(int mode, int inv, int log_e, unsigned grid, unsigned block,
                                                                    size_t lds, hipStream_t st, const GlpNttPassArgs* a) {
     if (log_e == 4) return launch_mode<4>(mode, inv, grid, block, lds, st, a);
 #if GLP_INST_LOG_R >= 9
     if (log_e == 5) return GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _e5)(mode, inv, grid, block, lds, st, a);
+#endif
+#if GLP_INST_LOG_R >= 11
+    if (log_e == 6) return GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _e6)(mode, inv, grid, block, lds, st, a);
 #endif
     return hipErrorInvalidValue;
 }

@@ -139,7 +139,7 @@ GL_HD u32 glp_bitrev32(u32 v, u32 bits) {
 // exchanged first, then the high words through the same [R][C+1] u32 array.  The LDS footprint per workgroup halves, so a CU holds four
 // workgroups of 32-element work-items instead of two: the radix-32 steps (one tile-twiddle layer and one exchange per 2^10 tile instead of
 // two) run at the occupancy the radix-16 kernel has (round 2 measured them at HALF of it: 0.97 vs 0.71 ms).
-template <int LOG_E, int MODE> struct GlpSplit { static constexpr bool value = (LOG_E == 5 && MODE != GLP_FINAL_ROWS); };
+template <int LOG_E, int MODE> struct GlpSplit { static constexpr bool value = (LOG_E >= 5 && MODE != GLP_FINAL_ROWS); };
 
 // PLAIN: a natural-order transform without the optional features — no coset blocks (LDE), no input scale, no per-element inter-pass table, no
 // bit-reversed placement, no polynomial-minor tile order.  Those are runtime switches of the general kernel; compiled out, their address
@@ -152,8 +152,9 @@ template <int LOG_E, int MODE> struct GlpSplit { static constexpr bool value = (
 // tiles at <= 256 threads (ntt_plan.h).
 template <int LOG_E, int MODE, int CT_LOG_C = -1> struct GlpBounds {
     // (a FINAL_T tile with a compile-time width needs 106 VGPRs: it may run 512 threads at four waves per SIMD)
-    static constexpr int threads = (LOG_E == 5 && MODE == GLP_FINAL_T) ? 256 : 1024;
-    static constexpr int waves = LOG_E == 5 ? (MODE == GLP_FINAL_T ? 3 : 4) : 1;
+    // radix-64 work-items (2^11 = 32 * 64 and 2^12 = 64 * 64 tiles: two register steps, ONE exchange): 128 VGPRs of data, two waves per SIMD
+    static constexpr int threads = LOG_E == 6 ? 512 : ((LOG_E == 5 && MODE == GLP_FINAL_T) ? 256 : 1024);
+    static constexpr int waves = LOG_E == 6 ? 2 : (LOG_E == 5 ? (MODE == GLP_FINAL_T ? 3 : 4) : 1);
 };
 // CT_LOG_C >= 0: the tile width is a compile-time constant (the host launches such an instantiation only when a.log_c equals it): every LDS
 // address becomes base + immediate offset — the runtime-width kernel keeps one address VGPR per element and side of the exchange (64 of

@@ -22,7 +22,7 @@ struct GlpPass {
     int log_r;     // tile transform size
     int mode;      // GLP_STRIP / GLP_FINAL_T / GLP_FINAL_ROWS
     int log_c;     // columns per tile
-    int log_e;     // elements per work-item (4 or 5)
+    int log_e;     // elements per work-item (4, 5 or 6)
     int log_m;     // STRIP: axis stride (log2); FINAL: 0
     int in_buf;    // GLP_BUF_*
     int out_buf;
@@ -45,6 +45,9 @@ static inline int glp_default_log_c(int log_r) {
 
 // radix-32 register steps exist (are instantiated) only for the tile sizes they shorten
 static inline int glp_has_e5(int log_r) { return log_r >= 9 && log_r <= 12; }
+// radix-64 work-items (round 3): 2^11 = 32 * 64 and 2^12 = 64 * 64 tiles in TWO register steps and ONE split exchange, so that 2^22 and 2^24 run
+// in two passes instead of three.  Plain natural-order transforms only (no coset / bit-reversed forms), tile widths 2^2 and 2^3 (compile-time).
+static inline int glp_has_e6(int log_r) { return log_r == 11 || log_r == 12; }
 static inline int glp_default_log_e(int log_r) { (void)log_r; return 4; }
 
 // Parse "r:c[:e],r:c[:e],..." (log2 radix : log2 columns [: log2 elements per work-item]);
@@ -109,11 +112,12 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
         ps->mode = last ? ((rev || np == 1) ? GLP_FINAL_ROWS : GLP_FINAL_T) : GLP_STRIP;
         ps->log_m = last ? 0 : rem;
         int e = le[i] >= 4 ? le[i] : glp_default_log_e(lr[i]);
-        if (e != 4 && !(e == 5 && glp_has_e5(lr[i]))) return -1;
+        if (e != 4 && !(e == 5 && glp_has_e5(lr[i])) && !(e == 6 && glp_has_e6(lr[i]) && !rev)) return -1;
         ps->log_e = e;
         const int tmin = 6 + e;                              // 64 .. 1024 threads; radix-32 FINAL_T tiles: <= 256 (GlpBounds, ntt_kernels.cuh)
-        const int tmax = (e == 5 && ps->mode == GLP_FINAL_T) ? 8 + e : 10 + e;
+        const int tmax = e == 6 ? 9 + e : ((e == 5 && ps->mode == GLP_FINAL_T) ? 8 + e : 10 + e);
         int c = lc[i] >= 0 ? lc[i] : glp_default_log_c(lr[i]);
+        if (e == 6) c = c < 2 ? 2 : (c > 3 ? 3 : c);       // the instantiated widths
         if (lc[i] < 0) {
             // small batches: prefer more, narrower tiles until the launch fills the chip
             // (>= 2 workgroups per CU), but never narrower than 32-byte segments
@@ -128,7 +132,7 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
         while (c > 0) {
             unsigned long long R = 1ull << lr[i], C = 1ull << c;
             unsigned long long el = R * C + (R > C ? R : C);
-            const unsigned long long bytes_per = (e == 5 && ps->mode != GLP_FINAL_ROWS) ? 4 : 8;   // split exchange: 32-bit halves (GlpSplit)
+            const unsigned long long bytes_per = (e >= 5 && ps->mode != GLP_FINAL_ROWS) ? 4 : 8;   // split exchange: 32-bit halves (GlpSplit)
             if (el * bytes_per <= 160 * 1024) break;
             c--;
         }
@@ -162,7 +166,7 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
 static inline size_t glp_pass_lds_bytes(const GlpPass* ps) {
     unsigned long long R = 1ull << ps->log_r, C = 1ull << ps->log_c;
     // radix-32 work-items exchange the tile as 32-bit halves (ntt_kernels.cuh, GlpSplit): half the footprint, except FINAL_ROWS (64-bit restaging)
-    if (ps->log_e == 5 && ps->mode != GLP_FINAL_ROWS) return (size_t)(R * (C + 1) * 4);
+    if (ps->log_e >= 5 && ps->mode != GLP_FINAL_ROWS) return (size_t)(R * (C + 1) * 4);
     unsigned long long a = R * (C + 1), b = (ps->mode == GLP_FINAL_ROWS) ? C * (R + 1) : 0;
     return (size_t)((a > b ? a : b) * 8);
 }

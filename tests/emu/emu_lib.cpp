@@ -61,7 +61,14 @@ struct EmuBackend {
                 }
                 glp_emu_launch(grid, block, lds, [&] { glp_ntt_pass_kernel<LR, MODE, INV, LE, false>(a); });
             };
-            if (ps.log_e == 5) {
+            if (ps.log_e == 6) {
+                // radix-64 work-items: PLAIN, compile-time tile width (what ntt_inst.hip instantiates)
+                if constexpr (LR >= 11 && MODE != GLP_FINAL_ROWS) {
+                    if (!glp_ntt_args_plain(a) || (a.log_c != 2 && a.log_c != 3)) { failed = true; return; }
+                    if (a.log_c == 2) glp_emu_launch(grid, block, lds, [&] { glp_ntt_pass_kernel<LR, MODE, INV, 6, true, 2>(a); });
+                    else glp_emu_launch(grid, block, lds, [&] { glp_ntt_pass_kernel<LR, MODE, INV, 6, true, 3>(a); });
+                } else failed = true;
+            } else if (ps.log_e == 5) {
                 if constexpr (LR >= 9) both(glp_ic<5>{});
             } else {
                 both(glp_ic<4>{});
@@ -77,7 +84,9 @@ struct EmuBackend {
             case 5: go(glp_ic<GLP_FINAL_ROWS>{}, glp_ic<1>{}); break;
         }
     }
+    bool failed = false;
     int launch_pass(const GlpPass& ps, int inv, unsigned long long grid, unsigned block, size_t lds, const GlpNttPassArgs& a) {
+        failed = false;
         switch (ps.log_r) {
             case 6: run<6>(ps, inv, (unsigned)grid, block, lds, a); break;
             case 7: run<7>(ps, inv, (unsigned)grid, block, lds, a); break;
@@ -88,7 +97,7 @@ struct EmuBackend {
             case 12: run<12>(ps, inv, (unsigned)grid, block, lds, a); break;
             default: return -10;
         }
-        return 0;
+        return failed ? -11 : 0;
     }
     int launch_small(const u64* src, u64* dst, u64 ss, u64 ds, u32 log_n, u32 batch, const u64* tw, u64 scale, u32 rev) {
         unsigned block = 64, grid = (batch + block - 1) / block;

@@ -50,6 +50,10 @@ CASES = [
     # natural order (strip + finalT, PLAIN instantiations), inverse with its scale, several polynomials, and FINAL_ROWS (64-bit restaging)
     (20, 1, 0, 0, "10:3:5,10:3:5", True), (18, 2, 1, 0, "12:2:5,6:4", False), (18, 1, 0, 0, "6:4,12:3:5", True), (17, 3, 0, 0, "11:3:5,6:3", True),
     (12, 2, 0, 0, "12:1:5", True), (11, 3, 1, 1, "11:2:5", False), (18, 1, 0, 1, "12:2:5,6:4", True),
+    # round 3: radix-64 work-items (2^11 = 32 * 64, 2^12 = 64 * 64: two register steps, one split exchange) — strip and finalT, both tile widths,
+    # forward and inverse, in place and out of place, more than one polynomial (the two-pass plans of 2^22 / 2^23 themselves ran here once, bit-exact, and on
+    # the GPU against the default plans: profiles/r03_ntt_e6_probe.jsonl)
+    (17, 2, 0, 0, "11:2:6,6:3", True), (17, 1, 1, 0, "6:3,11:3:6", False), (18, 1, 0, 0, "12:2:6,6:4", True), (18, 3, 1, 0, "6:4,12:3:6", True),
 ]
 
 
