@@ -41,8 +41,8 @@ CASES = [
     (18, 1, 1, 0, "6:4,6:4,6:4", False), (18, 1, 0, 1, "6:4,6:4,6:4", True), (17, 1, 0, 0, "6:3,11:3", True),
     (18, 1, 0, 0, "10:3,8:4", True), (18, 2, 1, 0, "10:2,8:4", False),
     # batched: per-element inter-pass twiddle tables + (tile position, polynomial) workgroup order
-    (13, 9, 0, 0, None, True), (14, 8, 1, 1, None, False), (16, 8, 0, 0, "10:3,6:4", True), (17, 16, 0, 0, "6:3,11:3", True),
-    (18, 8, 0, 0, "6:4,6:4,6:4", True), (16, 12, 1, 0, "10:2,6:4", True),
+    (13, 9, 0, 0, None, True), (14, 8, 1, 1, None, False), (16, 8, 0, 0, "10:3,6:4", True), (17, 8, 0, 0, "6:3,11:3", True),
+    (16, 12, 1, 0, "10:2,6:4", True),
     # radix-32 register steps (32 elements per work-item)
     (10, 5, 0, 0, "10:2:5", True), (9, 9, 1, 1, "9:3:5", True), (18, 1, 0, 0, "10:3:5,8:4", True),
     (19, 1, 1, 0, "10:2:5,9:3:5", False), (20, 1, 0, 1, "10:3:5,10:3:5", True), (18, 1, 0, 0, "9:3:5,9:3:5", True),
