@@ -98,7 +98,13 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
         // exchange per tile instead of two), 16 columns wide, with the split LDS exchange (ntt_kernels.cuh GlpSplit): -11 % VALU instructions,
         // 1.255 vs 1.373 ms at 128 x 2^20 in one run (profiles/r03_ntt_e5_probe.jsonl).  Small batches stay on the radix-16 kernels
         // (2^20 x 1: 49 vs 28 us), and so do bit-reversed / coset transforms (their general kernel has no registers to spare at 32 elements).
-        if (log_n == 20 && !rev && (batch << log_n) >= (1ull << 25)) { lc[0] = 4; lc[1] = 3; le[0] = le[1] = 5; }
+        const bool big = !rev && (batch << log_n) >= (1ull << 25);
+        if (log_n == 20 && big) { lc[0] = 4; lc[1] = 3; le[0] = le[1] = 5; }
+        // 2^22 and 2^24 in large batches (same-box A/B, profiles/r03_ntt_mixed_plans_probe.jsonl): 2^22 = 2^10 * 2^12 in TWO passes — the 2^10 strip
+        // kernel of the headline plan, then a FINAL_T pass of 2^12 = 64 * 64 on radix-64 work-items — 1.40 vs 1.48 ms at 32 x 2^22; 2^24 keeps three
+        // passes but starts with the same 2^10 strip kernel (10 + 7 + 7): 1.55 vs 1.58 ms at 8 x 2^24.  The pure radix-64 two-pass plans tie or lose.
+        if (log_n == 22 && big) { np = 2; lr[0] = 10; lr[1] = 12; lc[0] = 4; lc[1] = 3; le[0] = 5; le[1] = 6; }
+        if (log_n == 24 && big) { np = 3; lr[0] = 10; lr[1] = lr[2] = 7; lc[0] = 4; lc[1] = lc[2] = 5; le[0] = 5; le[1] = le[2] = 4; }
     }
     if (np > GLP_MAX_PASSES) return -1;
     pl->npass = np;
