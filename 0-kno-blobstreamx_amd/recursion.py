@@ -307,6 +307,179 @@ class CircuitBuilder:
             cur = self.poseidon(cur + list(sib) + [zero] * 4, swap=b)[:4]
         return cur
 
+    # ---- cloning a recorded segment ---------------------------------------------------------------------------------------------
+    # A recursion node verifies N proofs of ONE circuit: N copies of the same sub-circuit on different inputs.  Laying each copy down through the
+    # gadget code costs ~0.4 s of Python per child; the copies differ from the first only in their variable numbers and input tags, so they are
+    # made from the first one's recorded ops instead (numpy remapping), and every cloned variable's value comes from ONE run of the witness
+    # evaluator over what has been recorded.  The result is the circuit a direct build lays down (same cells, same copy classes: same key).
+    _OP_LEN = {0: 8, 1: 3, 2: 4, 3: 3, 4: 5, 6: 25, 11: 5, 12: 26, 13: 9}
+    _OP_VARS = {0: (1, 2, 3, 4), 1: (1,), 2: (1, 2), 3: (1, 2), 4: (1, 2, 3, 4), 6: tuple(range(1, 25)), 11: (1, 2), 12: tuple(range(1, 26)),
+                13: tuple(range(1, 9))}
+
+    def mark(self):
+        """a position in the recording (take one right after begin_segment() and one right before end_segment())"""
+        return {"vars": len(self.values), "prog": len(self.prog), "inputs": len(self.input_tags), "eq": len(self.eq_pairs), "wc": len(self.word_checks),
+                "public": len(self.public), "sha": len(self.sha_rows)}
+
+    def clone_segment(self, m0, m1, out, clones):
+        """Repeat the segment recorded between marks m0 and m1 once per entry of `clones` = [(retag, words), ...]: retag maps the list numbers of the
+        segment's input tags (and word checks) to the clone's, words(list number) -> that input list as an array of u64 words (the clone's free
+        inputs take their values from it).  `out`: any nesting of lists / tuples / dicts of variables the segment produced; returns its image per
+        clone.  The cloned variables' values are NOT valid until fill_values() has run.  Returns None (nothing recorded) when the segment uses ops
+        or state this does not copy (SHA rows, non-native products, public inputs, untagged inputs): the caller then lays the copies down directly."""
+        if m1["public"] != m0["public"] or m1["sha"] != m0["sha"] or getattr(self, "_open", False):
+            return None
+        v0, v1 = m0["vars"], m1["vars"]
+        w = self.prog[m0["prog"]:m1["prog"]]
+        offs = {op: [] for op in self._OP_LEN}
+        pos, n = 0, len(w)
+        while pos < n:
+            op = w[pos]
+            ln = self._OP_LEN.get(op)
+            if ln is None:
+                return None
+            offs[op].append(pos)
+            pos += ln
+        if pos != n:
+            return None
+        tags = self.input_tags[m0["inputs"]:m1["inputs"]]
+        if any(t is None for t in tags) or len(tags) != len(offs[1]):
+            return None
+        win = np.array(w, dtype=np.uint64)
+        offs = {op: np.array(o, dtype=np.int64) for op, o in offs.items()}
+        var_pos = np.concatenate([(offs[op][:, None] + np.array(self._OP_VARS[op], dtype=np.int64)[None, :]).ravel() for op in offs if offs[op].size])
+        inp_pos = offs[1] + 2
+        # constants first used inside the segment were recorded into the prefix: shared by every copy, never remapped
+        shared = np.array(sorted(v for c in self._consts.values() if c >= v0 for v in (c - 1, c)), dtype=np.int64)
+        # arithmetic gates by row constants, in recording order
+        a_off = offs[0]
+        if a_off.size:
+            keys = np.stack([win[a_off + 5], win[a_off + 6], win[a_off + 7]], axis=1)
+            uniq, inv = np.unique(keys, axis=0, return_inverse=True)
+            inv = inv.ravel()
+            groups = [(tuple(int(x) for x in uniq[g]), np.nonzero(inv == g)[0]) for g in range(uniq.shape[0])]
+        else:
+            groups = []
+        # Poseidon rows of both kinds, in recording order
+        p_off = np.concatenate([offs[6], offs[12]])
+        p_swap = np.concatenate([np.zeros(offs[6].size, dtype=bool), np.ones(offs[12].size, dtype=bool)])
+        order = np.argsort(p_off, kind="stable")
+        p_off, p_swap = p_off[order], p_swap[order]
+        e_off = offs[13]
+        eq = np.array(self.eq_pairs[m0["eq"]:m1["eq"]], dtype=np.int64).reshape(-1, 2)
+        wcs = self.word_checks[m0["wc"]:m1["wc"]]
+        in_vars = win[offs[1] + 1].astype(np.int64)                   # the segment's input variables, in input order
+        tag_pos = np.array([t[1] for t in tags], dtype=np.int64)
+        tag_list = [t[0] for t in tags]
+        zero = self.constant(0) if offs[6].size else None
+        per_row = self.R // 8
+
+        def image(x, lut):
+            if isinstance(x, dict):
+                return {k: image(v, lut) for k, v in x.items()}
+            if isinstance(x, (list, tuple)):
+                return type(x)(image(v, lut) for v in x)
+            return int(lut[x]) if isinstance(x, (int, np.integer)) and 0 <= x < v1 else x
+
+        results = []
+        for retag, words in clones:
+            base = len(self.values)
+            lut = np.arange(v1, dtype=np.int64)
+            lut[v0:v1] += base - v0
+            if shared.size:
+                lut[shared] = shared
+            cl = win.copy()
+            cl[var_pos] = lut[win[var_pos].astype(np.int64)].astype(np.uint64)
+            cl[inp_pos] = (win[inp_pos].astype(np.int64) - m0["inputs"] + len(self.input_tags)).astype(np.uint64)
+            self.values.extend([0] * (v1 - v0))
+            self.parent.extend(range(base, base + v1 - v0))
+            # free inputs: tags and values
+            new_lists = [retag[t] for t in tag_list]
+            self.input_tags.extend(zip(new_lists, tag_pos.tolist()))
+            cache = {}
+            for lid in set(new_lists):
+                cache[lid] = np.asarray(words(lid), dtype=np.uint64)
+            new_in = lut[in_vars]
+            for v, lid, p in zip(new_in.tolist(), new_lists, tag_pos.tolist()):
+                self.values[v] = int(cache[lid][p])
+            self.begin_segment()
+            self.prog.extend(cl.tolist())
+            self.end_segment()
+            # gates
+            for key, idx in groups:
+                o = a_off[idx]
+                slots = list(zip(cl[o + 2].tolist(), cl[o + 3].tolist(), cl[o + 4].tolist(), cl[o + 1].tolist()))
+                rows = self.arith_rows.setdefault(key, [[]])
+                room = self.G - len(rows[-1])
+                rows[-1].extend(slots[:room])
+                for i in range(room, len(slots), self.G):
+                    rows.append(slots[i:i + self.G])
+            if p_off.size:
+                outs_m = cl[p_off[:, None] + np.arange(1, 13)[None, :]].tolist()
+                ins_m = cl[p_off[:, None] + np.arange(13, 25)[None, :]].tolist()
+                sw = np.where(p_swap, cl[np.minimum(p_off + 25, cl.size - 1)], 0).tolist()
+                for ins_r, outs_r, has, sv in zip(ins_m, outs_m, p_swap.tolist(), sw):
+                    self.pos_rows.append((ins_r, outs_r, sv if has else zero))
+            if e_off.size:
+                cols = cl[e_off[:, None] + np.array([3, 4, 5, 6, 7, 8, 1, 2])[None, :]].tolist()
+                for t in cols:
+                    if len(self.ext_rows[-1]) == per_row:
+                        self.ext_rows.append([])
+                    self.ext_rows[-1].append(tuple(t))
+            # copy constraints, as assert_equal records them
+            if eq.size:
+                for a, b2 in lut[eq].tolist():
+                    ra, rb = self._find(a), self._find(b2)
+                    if ra != rb:
+                        self.parent[ra] = rb
+                        self.eq_pairs += (a, b2)
+            for c in wcs:
+                tag = (retag[c[1][0]], c[1][1])
+                if c[0] == "const":
+                    self.word_checks.append(("const", tag, c[2]))
+                elif c[0] == "var":
+                    self.word_checks.append(("var", tag, int(lut[c[2]])))
+                else:
+                    self.word_checks.append(("bits", tag, [int(lut[v]) for v in c[2]]))
+            results.append(image(out, lut))
+        self._stale_values = True
+        return results
+
+    def fill_values(self, poseidon_consts):
+        """after clone_segment: every variable's value from ONE run of the witness evaluator over what has been recorded (the clones' inputs were
+        set from their words); ValueError when a clone's inputs do not satisfy its copy constraints (e.g. a proof that does not verify)"""
+        import ctypes
+        import os
+        from . import load_library
+        if not getattr(self, "_stale_values", False):
+            return
+        lib = load_library()
+        rc, circ, diag = (np.ascontiguousarray(a, dtype=np.uint64) for a in poseidon_consts)
+        prog = np.array(self._prefix + self.prog, dtype=np.uint64)
+        pos, w, n = 0, self.prog, len(self.prog)
+        # the input vector: the value of each input variable (op 1: variable, input index), found by walking the ops
+        inputs = np.zeros(len(self.input_tags), dtype=np.uint64)
+        lens = {0: 8, 1: 3, 2: 4, 3: 3, 4: 5, 5: 2, 6: 25, 7: 10, 8: 6, 9: 6, 10: 4, 11: 5, 12: 26, 13: 9, 14: 24}
+        while pos < n:
+            op = w[pos]
+            if op == 1:
+                inputs[w[pos + 2]] = self.values[w[pos + 1]]
+            pos += lens[op]
+        vals = np.zeros(len(self.values), dtype=np.uint64)
+        bad = ctypes.c_size_t(0)
+        sb = np.array([len(self._prefix) + o for o in self.seg_bounds], dtype=np.uint64) if len(self.seg_bounds) > 2 else None
+        eqp = np.array(self.eq_pairs, dtype=np.uint64)
+        rcode = lib.glp_witness_eval_mt(rc.ctypes.data, circ.ctypes.data, diag.ctypes.data, prog.ctypes.data, prog.size,
+                                        inputs.ctypes.data if inputs.size else None, inputs.size, vals.ctypes.data, vals.size,
+                                        eqp.ctypes.data if eqp.size else None, eqp.size // 2, ctypes.byref(bad),
+                                        sb.ctypes.data if sb is not None else None, sb.size - 1 if sb is not None else 0, min(32, os.cpu_count() or 1))
+        if rcode == -7:
+            raise ValueError("a cloned segment's inputs do not satisfy the circuit (the witness evaluator refused them)")
+        if rcode != 0:
+            raise ValueError("witness program malformed after cloning")
+        self.values = vals.tolist()
+        self._stale_values = False
+
     # ---- layout ---------------------------------------------------------------------------------------------------------------
     def program(self):
         """the recorded circuit as a WitnessProgram: layout (constants, cells, sigma recipe) + the straight-line witness program"""

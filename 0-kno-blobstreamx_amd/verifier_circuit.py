@@ -18,6 +18,10 @@ variables of the child's public inputs and of its 4-word digest, for the caller 
 
 A proof that the native verifier rejects cannot be laid down: some ``assert_equal`` meets two different values and the builder raises.
 """
+import os
+
+import numpy as np
+
 from . import P
 from .recursion import FRI_TAG, PLONK_TAG
 
@@ -301,7 +305,6 @@ def verify_in_circuit(b, proof, leaf_key, num_queries, pow_bits, n_wires, n_rout
     sha: the child has SHA-256 rows (flag 2, ten constant columns): the 140 constraints of that block join the identity too.
     ext: the child has extension-arithmetic rows (flag 4, one more constant column, last): its chunks' multiply-add equations share the gate slots.
     Returns {"public": [vars], "digest": [4 vars]}."""
-    import numpy as np
     g = _G(b)
     words = [int(v) for v in np.frombuffer(bytes(proof), dtype="<u8")]
     pos = 0
@@ -672,15 +675,39 @@ class RecursionProgram:
         self.prover, self.consts = prover, poseidon_values
         b = CircuitBuilder(prover, n_wires=builder_wires, ext_gate=ext_gate)
         outs = []
-        for k, proof in enumerate(sample_proofs):
-            b.begin_segment()            # one proof's verifier depends on constants and on itself: the witness evaluator runs them in parallel
+
+        def spec_of(k):
             sp = dict(leaf_key=leaf_key, n_wires=n_wires, n_routed=n_routed, n_public=n_public, cap_height=cap_height,
                       child_is_recursion=child_is_recursion, child_sha=child_sha, child_ext=child_ext)
             if specs is not None:
                 sp.update(specs[k])
+            return sp
+
+        def same_circuit(a, c):
+            return (all(np.array_equal(np.asarray(a[f]), np.asarray(c[f])) if f == "leaf_key" else a[f] == c[f] for f in a))
+
+        clone = os.environ.get("GLP_RECORD_CLONE", "1") != "0"
+        k = 0
+        while k < n:
+            proof, sp = sample_proofs[k], spec_of(k)
+            b.begin_segment()            # one proof's verifier depends on constants and on itself: the witness evaluator runs them in parallel
+            m0 = b.mark()
             outs.append(verify_in_circuit(b, proof, sp["leaf_key"], num_queries, pow_bits, sp["n_wires"], sp["n_routed"], sp["n_public"], sp["cap_height"],
                                           poseidon_values if sp["child_is_recursion"] else None, proof_id=k, sha=sp["child_sha"], ext=sp["child_ext"]))
+            m1 = b.mark()
             b.end_segment()
+            k += 1
+            # the following proofs of the SAME circuit: copies of the sub-circuit just recorded (CircuitBuilder.clone_segment) instead of
+            # another pass through the gadget code
+            j = k
+            while clone and j < n and len(sample_proofs[j]) == len(proof) and same_circuit(spec_of(j), sp):
+                j += 1
+            if j > k:
+                got = b.clone_segment(m0, m1, outs[-1], [({k - 1: jj}, (lambda lid, jj=jj: np.frombuffer(bytes(sample_proofs[jj]), dtype="<u8"))) for jj in range(k, j)])
+                if got is not None:
+                    outs += got
+                    k = j
+        b.fill_values(poseidon_values)   # the clones' values, from one run of the witness evaluator (ValueError: one of the proofs does not verify)
         if combine is None:
             level = []
             for out in outs:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/soak_signatures.py <seconds> — soak of the signature-set MapReduce (signature_mr.py) on one GPU: random validator sets (2..8 validators
-padded to a power of two, random flags, random keys and votes), each proved to a root that must verify for the host-computed signer digest and
+"""profiles/soak_signatures.py <seconds> — soak of the signature-set MapReduce (signature_mr.py) on one GPU: random validator sets (2..14 validators:
+the digest pads to a power of two, the tree proves only the groups that hold a validator and enters the all-padding groups as constants, random flags, random keys and votes), each proved to a root that must verify for the host-computed signer digest and
 block hash; every second set is then corrupted in one random way — a flipped signature bit of a flagged slot, a flagged slot signed by another key,
 a vote naming another block, a flag without a signature — and must be REFUSED (ValueError before or while folding).  6 queries / 4 PoW bits."""
 import hashlib
@@ -31,8 +31,12 @@ mr = sm.SignatureSetMapReduce(provers[0], consts, msg_len=64, hash_offset=12, fa
 rng = random.Random(2024)
 t_end = time.time() + budget
 stats = {"sets": 0, "slots": 0, "flagged": 0, "accepted": 0, "corrupted": 0, "refused": 0, "by_kind": {}}
+t_mark = time.time()
 while time.time() < t_end:
-    n = rng.randint(2, 8)
+    if time.time() - t_mark > 60:                            # a progress line a minute (a silent run looks hung to the GPU runner)
+        t_mark = time.time()
+        print(json.dumps({"progress": {k: stats[k] for k in ("sets", "accepted", "corrupted", "refused")}}), flush=True)
+    n = rng.randint(2, 14)
     block = hashlib.sha256(str(rng.random()).encode()).digest()
     seeds = [bytes(rng.randrange(256) for _ in range(32)) for _ in range(n)]
     msgs = [mr.vote_bytes(block, rng.randrange(1000)) for _ in range(n)]
@@ -51,6 +55,8 @@ while time.time() < t_end:
     ok = ok and not mr.verify_set(out["root_proof"], out["key"], block, other)
     stats["sets"] += 1
     stats["slots"] += total
+    stats["leaves_proved"] = stats.get("leaves_proved", 0) + out["slots"]
+    stats["trimmed_sets"] = stats.get("trimmed_sets", 0) + (out["slots"] < total)
     stats["flagged"] += sum(flags)
     stats["accepted"] += bool(ok)
     if not ok:

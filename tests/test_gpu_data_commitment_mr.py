@@ -234,3 +234,39 @@ def test_data_commitment_4096_blocks_at_baseline_size(prover, oracle, pkg):
     mr.free()
     for p in extra:
         p.close()
+
+
+@pytest.mark.gpu
+def test_cloned_node_circuits_are_the_directly_built_ones(prover, oracle, pkg, monkeypatch):
+    """A node circuit verifies its 2nd..Nth child through CLONES of the first child's recorded sub-circuit (CircuitBuilder.clone_segment).  The same
+    range proved with cloning off (every child laid down through the gadget code): identical verifying keys at every level, identical root
+    statement; each root is accepted under the other run's key; a bad leaf among the cloned children still stops the fold."""
+    dm = importlib.import_module(graft.PKG_NAME + ".data_commitment_mr")
+    consts = poseidon_consts("small")
+    prover.set_poseidon_constants(*consts)
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    rng = np.random.default_rng(77)
+    heights = [9_000_000 + k for k in range(16)]
+    roots = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in heights]
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GLP_RECORD_CLONE", mode)
+        mr = dm.DataCommitmentMapReduce(prover, consts, leaf_blocks=2, fan_in=4, num_queries=6, pow_bits=4)
+        out = mr.prove_range(heights, roots)                 # 8 distinct leaf proofs -> 2 nodes of 4 -> root of 2
+        keys = sorted((k[0], k[1], bytes(np.ascontiguousarray(p.key(), dtype=np.uint64))) for k, p in mr.nodes.items())
+        runs[mode] = (mr, out, keys)
+    (mr0, out0, keys0), (mr1, out1, keys1) = runs["0"], runs["1"]
+    assert [k[:2] for k in keys0] == [(1, 4), (2, 2)] and keys0 == keys1, "a cloned node circuit differs from the directly built one"
+    assert np.array_equal(out0["key"], out1["key"]) and out0["public"] == out1["public"] and out0["commitment"] == _root(heights, roots)
+    assert mr0.verify(out1["root_proof"], out0["key"], heights, roots, out1["commitment"]), prover.last_reject
+    assert mr1.verify(out0["root_proof"], out1["key"], heights, roots, out0["commitment"]), prover.last_reject
+    pref.verify_plonk(out1["root_proof"], oracle, pos_consts=consts, public=out1["public"])
+    # a FRESH object recording its node from a batch whose third child is bad: the clone's witness is refused
+    mr2 = dm.DataCommitmentMapReduce(prover, consts, leaf_blocks=2, fan_in=4, num_queries=6, pow_bits=4)
+    leaves = mr2.prove_leaves(heights[:8], roots[:8])
+    w = np.frombuffer(leaves[2], dtype="<u8").copy()
+    w[len(w) // 2] ^= np.uint64(1)
+    with pytest.raises(ValueError):
+        mr2.reduce(leaves[:2] + [w.tobytes()] + leaves[3:])
+    for m in (mr0, mr1, mr2):
+        m.free()

@@ -229,3 +229,77 @@ def test_recursion_program_recorded_once_proves_other_batches(prover, oracle, pk
     rp2.free()
     rp.free()
     ck.free()
+
+
+@pytest.mark.parametrize("which,ext", [("plonk", False), ("gates", False), ("sha", True)])
+def test_cloned_verifier_segments_equal_direct_ones(oracle, which, ext):
+    """CircuitBuilder.clone_segment (what RecursionProgram records its 2nd..Nth child with): three verifier sub-circuits laid down through the gadget
+    code vs ONE laid down and cloned twice — the same constants, the same rows, the same copy classes over the same cells (hence the same circuit
+    key), the same wire values for new inputs, the same refusals."""
+    rec, vc, _, _ = _mods()
+    consts = poseidon_consts("small")
+    oracle.orc_poseidon_set_constants(*(ptr(a) for a in consts))
+    with open(os.path.join(G, "proofs.json")) as f:
+        g = json.load(f)[which]
+    proof = bytes.fromhex(g["proof"])
+    kw = dict(n_routed=g.get("R"), n_public=g.get("n_public", 0), poseidon_consts=consts if which != "plonk" else None, sha=which == "sha")
+    args = (g["circuit_cap"], g["queries"], g["pow_bits"], g["W"])
+    direct = rec.CircuitBuilder(_oracle_prover(oracle), ext_gate=ext)
+    outs_d = []
+    for k in range(3):
+        direct.begin_segment()
+        outs_d.append(vc.verify_in_circuit(direct, proof, *args, proof_id=k, **kw))
+        direct.end_segment()
+    cloned = rec.CircuitBuilder(_oracle_prover(oracle), ext_gate=ext)
+    cloned.begin_segment()
+    m0 = cloned.mark()
+    out0 = vc.verify_in_circuit(cloned, proof, *args, proof_id=0, **kw)
+    m1 = cloned.mark()
+    cloned.end_segment()
+    words = lambda lid: np.frombuffer(proof, dtype="<u8")
+    got = cloned.clone_segment(m0, m1, out0, [({0: 1}, words), ({0: 2}, words)])
+    assert got is not None, "the verifier sub-circuit uses something clone_segment does not copy"
+    cloned.fill_values(consts)
+    outs_c = [out0] + got
+    for od, oc in zip(outs_d, outs_c):
+        for key in ("public", "digest"):
+            assert [direct.value(v) for v in od[key]] == [cloned.value(v) for v in oc[key]]
+    for b in (direct, cloned):                       # a statement after the segments (reads the values fill_values wrote)
+        for v in b.two_to_one(outs_d[0]["digest"] if b is direct else outs_c[0]["digest"], outs_d[2]["digest"] if b is direct else outs_c[2]["digest"]):
+            b.public_input(v)
+    pd, pc = direct.program(), cloned.program()
+    assert pd.log_n == pc.log_n and {k: v for k, v in pd.stats.items() if k != "variables"} == {k: v for k, v in pc.stats.items() if k != "variables"}
+    assert np.array_equal(pd.consts, pc.consts)
+    assert np.array_equal(pd.cell_index >= pd.n_values, pc.cell_index >= pc.n_values)      # empty cells and cells holding a fixed constant
+    assert np.array_equal(pd.fixed, pc.fixed)
+    used_d, used_c = pd.cell_index < pd.n_values, pc.cell_index < pc.n_values
+    cls_d, cls_c = pd.roots[pd.cell_index[used_d].astype(np.int64)], pc.roots[pc.cell_index[used_c].astype(np.int64)]
+    pairs = np.unique(np.stack([cls_d, cls_c], axis=1), axis=0)
+    assert np.unique(cls_d).size == np.unique(cls_c).size == pairs.shape[0], "the copy classes over the cells differ"
+    assert np.array_equal(pd.input_tags, pc.input_tags) and np.array_equal(pd.wc_const, pc.wc_const) and np.array_equal(pd.wc_bits, pc.wc_bits)
+    # new inputs through both programs: the same wire matrix
+    wires = []
+    for p in (pd, pc):
+        inputs, ws = p.inputs_from_words([proof] * 3)
+        vals = p.evaluate(consts, inputs)
+        p.check_words(vals, ws)
+        full = np.concatenate([vals, p.fixed_values, np.zeros(1, dtype=np.uint64)])
+        idx = np.where(p.cell_index == 0xFFFFFFFF, full.size - 1, p.cell_index).astype(np.int64)
+        wires.append(full[idx])
+    assert np.array_equal(wires[0], wires[1])
+    bad = np.frombuffer(proof, dtype="<u8").copy()
+    bad[len(bad) // 2] ^= np.uint64(1)
+    for p in (pd, pc):
+        with pytest.raises(ValueError):
+            i2, ws2 = p.inputs_from_words([proof, proof, bad.tobytes()])
+            p.check_words(p.evaluate(consts, i2), ws2)
+    # a clone whose inputs do not verify: refused by fill_values, as the gadget code refuses to lay such a proof down
+    c2 = rec.CircuitBuilder(_oracle_prover(oracle), ext_gate=ext)
+    c2.begin_segment()
+    m0 = c2.mark()
+    o0 = vc.verify_in_circuit(c2, proof, *args, proof_id=0, **kw)
+    m1 = c2.mark()
+    c2.end_segment()
+    assert c2.clone_segment(m0, m1, o0, [({0: 1}, lambda lid: bad)]) is not None
+    with pytest.raises(ValueError):
+        c2.fill_values(consts)
