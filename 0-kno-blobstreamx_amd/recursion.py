@@ -509,56 +509,75 @@ class WitnessProgram:
         self.log_n = max(3, (max(n_rows, 1) - 1).bit_length())
         n = 1 << self.log_n
         consts = np.zeros((PLONK_NCONST + (4 if self.has_sha else 0) + (1 if self.has_ext else 0), n), dtype=np.uint64)
-        fixed = []                                   # (wire, row, value): cells of unused gate slots that must hold c2
-        cj, ci, cv = [], [], []                      # placed cells: wire, row, variable
-        i = 0
-        for v in b.public:
-            consts[4, i] = 1
-            cj.append(0); ci.append(i); cv.append(v)
-            i += 1
-        self.pos_row_ids = []
-        for ins, outs, swap in b.pos_rows:
-            consts[5, i] = 1
-            for j, v in enumerate(ins):
-                cj.append(j); ci.append(i); cv.append(v)
-            for j, v in enumerate(outs):
-                cj.append(12 + j); ci.append(i); cv.append(v)
-            cj.append(24); ci.append(i); cv.append(swap)                # GLP_POS_SWAP_WIRE: an index bit, or the constant 0 (never a free cell)
-            self.pos_row_ids.append(i)
-            i += 1
-        sha_ids, sha_kinds = [], []
-        for kind, words, k_const in b.sha_rows:
-            consts[6 + kind, i], consts[3, i] = 1, k_const
-            for j, v in enumerate(words):
-                cj.append(j); ci.append(i); cv.append(v)
-            sha_ids.append(i)
-            sha_kinds.append(kind)
-            i += 1
-        self.sha_row_ids, self.sha_kinds = np.array(sha_ids, dtype=np.uint32), np.array(sha_kinds, dtype=np.uint32)
+        # placed cells (wire, row, variable), in the order public inputs, Poseidon rows, SHA rows, extension rows, arithmetic rows by constants —
+        # row by row, cell by cell: setup() links the cells of a copy class in THIS order, so it is part of what the circuit's key is a function of.
+        # Built with numpy (a signature leaf has 2.2 M gate slots, a recursion node 0.8 M: the per-slot Python loop was half of a recording).
+        from itertools import chain
+        I64 = np.int64
+        cjs, cis, cvs = [], [], []
+
+        def flat(it, count):
+            return np.fromiter(it, dtype=I64, count=count)
+        i = len(b.public)
+        consts[4, :i] = 1
+        cjs.append(np.zeros(i, dtype=I64)); cis.append(np.arange(i, dtype=I64)); cvs.append(flat(iter(b.public), i))
+        npos = len(b.pos_rows)
+        self.pos_row_ids = np.arange(i, i + npos, dtype=np.uint32)
+        if npos:
+            consts[5, i:i + npos] = 1
+            cells = np.empty((npos, 25), dtype=I64)
+            cells[:, :12] = flat(chain.from_iterable(r[0] for r in b.pos_rows), 12 * npos).reshape(npos, 12)
+            cells[:, 12:24] = flat(chain.from_iterable(r[1] for r in b.pos_rows), 12 * npos).reshape(npos, 12)
+            cells[:, 24] = flat((r[2] for r in b.pos_rows), npos)                 # GLP_POS_SWAP_WIRE: an index bit, or the constant 0 (never a free cell)
+            cjs.append(np.tile(np.arange(25, dtype=I64), npos)); cis.append(np.repeat(np.arange(i, i + npos, dtype=I64), 25)); cvs.append(cells.ravel())
+            i += npos
+        nsha = len(b.sha_rows)
+        self.sha_row_ids = np.arange(i, i + nsha, dtype=np.uint32)
+        self.sha_kinds = np.fromiter((r[0] for r in b.sha_rows), dtype=np.uint32, count=nsha)
+        if nsha:
+            consts[6 + self.sha_kinds.astype(I64), np.arange(i, i + nsha)] = 1
+            consts[3, i:i + nsha] = np.fromiter((r[2] for r in b.sha_rows), dtype=np.uint64, count=nsha)
+            lens = np.fromiter((len(r[1]) for r in b.sha_rows), dtype=I64, count=nsha)
+            tot = int(lens.sum())
+            first = np.cumsum(lens) - lens
+            cjs.append(np.arange(tot, dtype=I64) - np.repeat(first, lens)); cis.append(np.repeat(np.arange(i, i + nsha, dtype=I64), lens))
+            cvs.append(flat(chain.from_iterable(r[1] for r in b.sha_rows), tot))
+            i += nsha
         for row in ext_rows:                                             # q_ext is the LAST constant column
             consts[-1, i] = 1
-            for c, op in enumerate(row):
-                for k, v in enumerate(op):
-                    cj.append(8 * c + k); ci.append(i); cv.append(v)
+            m = len(row)
+            cjs.append(np.arange(8 * m, dtype=I64)); cis.append(np.full(8 * m, i, dtype=I64)); cvs.append(flat(chain.from_iterable(row), 8 * m))
             i += 1
-        for (c0, c1, c2), row in arith:
-            consts[0, i], consts[1, i], consts[2, i], consts[3, i] = 1, c0, c1, c2
-            for g, slot in enumerate(row):
-                base = 4 * g
-                cj += (base, base + 1, base + 2, base + 3)
-                ci += (i, i, i, i)
-                cv += slot
-            if len(row) < G and c2:
-                fixed += [(4 * g + 3, i, c2) for g in range(len(row), G)]      # an unused slot must still satisfy its gate: w = c2
-            i += 1
+        fixed = []                                   # (wire, row, value): cells of unused gate slots that must hold c2
+        by_key = {}
+        for key, row in arith:
+            by_key.setdefault(key, []).append(row)
+        for (c0, c1, c2), rows in by_key.items():     # (`arith` is sorted by key: so is by_key)
+            nr = len(rows)
+            consts[0, i:i + nr], consts[1, i:i + nr], consts[2, i:i + nr], consts[3, i:i + nr] = 1, c0, c1, c2
+            lens = np.fromiter((len(r) for r in rows), dtype=I64, count=nr)
+            ns = int(lens.sum())
+            slots = flat(chain.from_iterable(chain.from_iterable(rows)), 4 * ns)
+            srow = np.repeat(np.arange(i, i + nr, dtype=I64), lens)                        # row of each slot
+            sg = np.arange(ns, dtype=I64) - np.repeat(np.cumsum(lens) - lens, lens)         # its position in the row
+            cjs.append((4 * sg[:, None] + np.arange(4, dtype=I64)[None, :]).ravel()); cis.append(np.repeat(srow, 4)); cvs.append(slots)
+            if c2:
+                for r in np.nonzero(lens < G)[0].tolist():
+                    fixed += [(4 * g + 3, i + r, c2) for g in range(int(lens[r]), G)]      # an unused slot must still satisfy its gate: w = c2
+            i += nr
         self.consts = consts
-        self.cj, self.ci, self.cv = np.array(cj, dtype=np.int64), np.array(ci, dtype=np.int64), np.array(cv, dtype=np.int64)
+        self.cj, self.ci, self.cv = np.concatenate(cjs), np.concatenate(cis), np.concatenate(cvs)
         if self.cj.size and int(self.cj.max()) >= R:
             raise ValueError("a variable sits on an unrouted wire")
         self.fixed = np.array(fixed, dtype=np.uint64).reshape(-1, 3)
-        self.pos_row_ids = np.array(self.pos_row_ids, dtype=np.uint32)
         self.public_vars = np.array(b.public, dtype=np.int64)
-        self.roots = np.array([b._find(v) for v in range(len(b.parent))], dtype=np.int64)
+        par = np.array(b.parent, dtype=np.int64)                          # union-find roots by pointer jumping (1.4 M variables: no Python loop)
+        while True:
+            nxt = par[par]
+            if np.array_equal(nxt, par):
+                break
+            par = nxt
+        self.roots = par
         self.n_values = len(b.values)
         self.prog = np.array(b._prefix + b.prog, dtype=np.uint64)
         self.seg_bounds = np.array([len(b._prefix) + o for o in b.seg_bounds], dtype=np.uint64) if len(b.seg_bounds) > 2 else None
