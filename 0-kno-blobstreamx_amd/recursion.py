@@ -13,10 +13,22 @@ rows), the recorded circuit (``WitnessProgram``: layout + straight-line witness 
 digests into a Poseidon Merkle root, in-circuit Merkle paths.  The in-circuit VERIFIER of leaf proofs is verifier_circuit.py; the SHA-256 gadgets and
 the statements on them are gadgets.py.
 """
+from array import array
+
 import numpy as np
 
 from . import (CIRCUIT_POSEIDON_GATE, P, PLONK_NCONST, PLONK_NCONST_SHA, POS_GATE_WIRES, SHA_GATE_WIRES, SHA_ROW_A, SHA_ROW_ADD, SHA_ROW_E,  # noqa: F401
                SHA_ROW_W, DeviceBuffer, PlonkCircuit)
+
+
+class _Words(array):
+    """the flat op words of a recording as a C array of u64 (`+=` a tuple of ints appends it): a signature leaf records 10 M words, and turning a
+    Python list of that length into numpy was a second of every recording; this one is viewed by numpy in place"""
+    __slots__ = ()
+
+    def __iadd__(self, words):
+        self.extend(words)
+        return self
 
 
 class CircuitBuilder:
@@ -37,8 +49,8 @@ class CircuitBuilder:
         self.public = []
         self._consts = {}
         # the straight-line program that recomputes every variable from the free inputs (WitnessProgram / glp_witness_eval)
-        self.prog = []                   # flat op words (encoding: csrc/verify.hip)
-        self._prefix = []                # ops of the constants: they run first, every segment may read them
+        self.prog = _Words("Q")         # flat op words (encoding: csrc/verify.hip)
+        self._prefix = _Words("Q")      # ops of the constants: they run first, every segment may read them
         self.seg_bounds = []             # offsets into prog: [start_0, end_0 = start_1, ..., end_last] of the independent segments
         self.input_tags = []             # per free input: caller's tag (e.g. (proof number, word position)) or None
         self.eq_pairs = []               # copy constraints between different variables
@@ -117,13 +129,21 @@ class CircuitBuilder:
     # ---- gates ----------------------------------------------------------------------------------------------------------------
     def arith(self, c0, c1, c2, x, y, z):
         """w = c0*x*y + c1*z + c2 (one slot of a row whose constants are (c0, c1, c2))"""
-        key = (int(c0) % P, int(c1) % P, int(c2) % P)
-        w = self._new(key[0] * self.values[x] * self.values[y] + key[1] * self.values[z] + key[2])
-        self.prog += (0, w, x, y, z, key[0], key[1], key[2])
-        rows = self.arith_rows.setdefault(key, [[]])
-        if len(rows[-1]) == self.G:
-            rows.append([])
-        rows[-1].append((x, y, z, w))
+        k0, k1, k2 = int(c0) % P, int(c1) % P, int(c2) % P
+        vals = self.values
+        w = len(vals)                                            # (_new, inlined: this is the builder's hottest function — a million calls per signature)
+        vals.append((k0 * vals[x] * vals[y] + k1 * vals[z] + k2) % P)
+        self.parent.append(w)
+        self.prog.extend((0, w, x, y, z, k0, k1, k2))
+        key = (k0, k1, k2)
+        rows = self.arith_rows.get(key)
+        if rows is None:
+            rows = self.arith_rows[key] = [[]]
+        last = rows[-1]
+        if len(last) == self.G:
+            last = []
+            rows.append(last)
+        last.append((x, y, z, w))
         return w
 
     def constant(self, k):
@@ -345,7 +365,7 @@ class CircuitBuilder:
         tags = self.input_tags[m0["inputs"]:m1["inputs"]]
         if any(t is None for t in tags) or len(tags) != len(offs[1]):
             return None
-        win = np.array(w, dtype=np.uint64)
+        win = np.frombuffer(w, dtype=np.uint64)
         offs = {op: np.array(o, dtype=np.int64) for op, o in offs.items()}
         var_pos = np.concatenate([(offs[op][:, None] + np.array(self._OP_VARS[op], dtype=np.int64)[None, :]).ravel() for op in offs if offs[op].size])
         inp_pos = offs[1] + 2
@@ -403,7 +423,7 @@ class CircuitBuilder:
             for v, lid, p in zip(new_in.tolist(), new_lists, tag_pos.tolist()):
                 self.values[v] = int(cache[lid][p])
             self.begin_segment()
-            self.prog.extend(cl.tolist())
+            self.prog.frombytes(cl.tobytes())
             self.end_segment()
             # gates
             for key, idx in groups:
@@ -455,7 +475,7 @@ class CircuitBuilder:
             return
         lib = load_library()
         rc, circ, diag = (np.ascontiguousarray(a, dtype=np.uint64) for a in poseidon_consts)
-        prog = np.array(self._prefix + self.prog, dtype=np.uint64)
+        prog = np.frombuffer(self._prefix + self.prog, dtype=np.uint64)
         pos, w, n = 0, self.prog, len(self.prog)
         # the input vector: the value of each input variable (op 1: variable, input index), found by walking the ops
         inputs = np.zeros(len(self.input_tags), dtype=np.uint64)
@@ -579,7 +599,7 @@ class WitnessProgram:
             par = nxt
         self.roots = par
         self.n_values = len(b.values)
-        self.prog = np.array(b._prefix + b.prog, dtype=np.uint64)
+        self.prog = np.frombuffer(b._prefix + b.prog, dtype=np.uint64)       # (a view of the concatenation, which nothing else holds)
         self.seg_bounds = np.array([len(b._prefix) + o for o in b.seg_bounds], dtype=np.uint64) if len(b.seg_bounds) > 2 else None
         tags = b.input_tags
         if tags and all(t is not None for t in tags):
