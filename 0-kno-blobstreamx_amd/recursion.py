@@ -21,6 +21,9 @@ from . import (CIRCUIT_POSEIDON_GATE, P, PLONK_NCONST, PLONK_NCONST_SHA, POS_GAT
                SHA_ROW_W, DeviceBuffer, PlonkCircuit)
 
 
+_OP_WORDS = {0: 8, 1: 3, 2: 4, 3: 3, 4: 5, 5: 2, 6: 25, 7: 10, 8: 6, 9: 6, 10: 4, 11: 5, 12: 26, 13: 9, 14: 24}   # words per op (csrc/verify.hip)
+
+
 class _Words(array):
     """the flat op words of a recording as a C array of u64 (`+=` a tuple of ints appends it): a signature leaf records 10 M words, and turning a
     Python list of that length into numpy was a second of every recording; this one is viewed by numpy in place"""
@@ -332,7 +335,8 @@ class CircuitBuilder:
     # gadget code costs ~0.4 s of Python per child; the copies differ from the first only in their variable numbers and input tags, so they are
     # made from the first one's recorded ops instead (numpy remapping), and every cloned variable's value comes from ONE run of the witness
     # evaluator over what has been recorded.  The result is the circuit a direct build lays down (same cells, same copy classes: same key).
-    _OP_LEN = {0: 8, 1: 3, 2: 4, 3: 3, 4: 5, 6: 25, 11: 5, 12: 26, 13: 9}
+    _OP_WORDS = _OP_WORDS
+    _OP_LEN = {op: n for op, n in _OP_WORDS.items() if op in (0, 1, 2, 3, 4, 6, 11, 12, 13)}                        # the ops clone_segment copies
     _OP_VARS = {0: (1, 2, 3, 4), 1: (1,), 2: (1, 2), 3: (1, 2), 4: (1, 2, 3, 4), 6: tuple(range(1, 25)), 11: (1, 2), 12: tuple(range(1, 26)),
                 13: tuple(range(1, 9))}
 
@@ -479,7 +483,7 @@ class CircuitBuilder:
         pos, w, n = 0, self.prog, len(self.prog)
         # the input vector: the value of each input variable (op 1: variable, input index), found by walking the ops
         inputs = np.zeros(len(self.input_tags), dtype=np.uint64)
-        lens = {0: 8, 1: 3, 2: 4, 3: 3, 4: 5, 5: 2, 6: 25, 7: 10, 8: 6, 9: 6, 10: 4, 11: 5, 12: 26, 13: 9, 14: 24}
+        lens = self._OP_WORDS
         while pos < n:
             op = w[pos]
             if op == 1:
