@@ -374,7 +374,7 @@ class CircuitBuilder:
         var_pos = np.concatenate([(offs[op][:, None] + np.array(self._OP_VARS[op], dtype=np.int64)[None, :]).ravel() for op in offs if offs[op].size])
         inp_pos = offs[1] + 2
         # constants first used inside the segment were recorded into the prefix: shared by every copy, never remapped
-        shared = np.array(sorted(v for c in self._consts.values() if c >= v0 for v in (c - 1, c)), dtype=np.int64)
+        shared = np.array(sorted(v for c in self._consts.values() if v0 <= c < v1 for v in (c - 1, c)), dtype=np.int64)
         # arithmetic gates by row constants, in recording order
         a_off = offs[0]
         if a_off.size:
