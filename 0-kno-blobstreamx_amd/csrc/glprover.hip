@@ -469,7 +469,7 @@ extern "C" int glp_ntt_describe_plan(glp_ctx* c, uint32_t log_n, uint32_t batch,
     static const char* mn[] = {"strip", "finalT", "finalRows"};
     for (int i = 0; i < pl.npass && off < len; i++)
         off += (size_t)snprintf(buf + off, len - off, "%s%s(R=2^%d,C=2^%d%s)", i ? "+" : "", mn[pl.p[i].mode], pl.p[i].log_r, pl.p[i].log_c,
-                                pl.p[i].log_e == 5 ? ",E=32" : (pl.p[i].log_e == 6 ? ",E=64" : ""));
+                                pl.p[i].log_e == 5 ? ",E=32" : (pl.p[i].log_e == 6 ? ",E=64" : (pl.p[i].log_e == 3 ? ",E=8" : (pl.p[i].log_e == 2 ? ",E=4" : ""))));
     return GLP_OK;
 }
 

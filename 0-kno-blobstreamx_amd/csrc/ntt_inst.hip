@@ -112,6 +112,10 @@ extern "C" hipError_t GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _
 extern "C" hipError_t GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R)(int mode, int inv, int log_e, unsigned grid, unsigned block,
                                                                    size_t lds, hipStream_t st, const GlpNttPassArgs* a) {
     if (log_e == 4) return launch_mode<4>(mode, inv, grid, block, lds, st, a);
+#if GLP_INST_LOG_R == 10
+    if (log_e == 2) return launch_mode<2>(mode, inv, grid, block, lds, st, a);
+    if (log_e == 3) return launch_mode<3>(mode, inv, grid, block, lds, st, a);   // 8-element work-items: twice the waves for latency-bound single transforms
+#endif
 #if GLP_INST_LOG_R >= 9
     if (log_e == 5) return GLP_CAT(GLP_CAT(glp_launch_ntt_pass_lr, GLP_INST_LOG_R), _e5)(mode, inv, grid, block, lds, st, a);
 #endif

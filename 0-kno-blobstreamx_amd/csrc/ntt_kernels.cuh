@@ -96,7 +96,8 @@ static inline bool glp_ntt_args_plain(const GlpNttPassArgs& a) {
     return !a.coset_log && !a.src_coset && !a.in_row && !a.in_col && !a.tw_full && !a.poly_minor && !a.rev;
 }
 
-// LOG_E = log2 of the elements held per work-item (4: radix <= 16 steps, 5: radix <= 32 steps)
+// LOG_E = log2 of the elements held per work-item (4: radix <= 16 steps, 5: radix <= 32 steps, 6: radix <= 64 steps on 2^11 / 2^12 tiles;
+// 2 and 3: small work-items for latency-bound single transforms of 2^20 — more waves per CU, more register steps)
 template <int LOG_R, int LOG_E>
 struct GlpSteps {
     static constexpr int S = (LOG_R + LOG_E - 1) / LOG_E;                       // register steps

@@ -103,6 +103,12 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
         // 2^22 and 2^24 in large batches (same-box A/B, profiles/r03_ntt_mixed_plans_probe.jsonl): 2^22 = 2^10 * 2^12 in TWO passes — the 2^10 strip
         // kernel of the headline plan, then a FINAL_T pass of 2^12 = 64 * 64 on radix-64 work-items — 1.40 vs 1.48 ms at 32 x 2^22; 2^24 keeps three
         // passes but starts with the same 2^10 strip kernel (10 + 7 + 7): 1.55 vs 1.58 ms at 8 x 2^24.  The pure radix-64 two-pass plans tie or lose.
+        // single (and paired) 2^20 transforms are latency-bound — 1024 waves of 16-element work-items are ONE wave per SIMD, each walking its
+        // dependent chain with nothing to overlap its loads, exchanges and stores with: 4-element work-items (five register steps, 16 waves per CU)
+        // run 2^20 x 1 in 21.6 instead of 26.5 us, 8-element work-items 2^20 x 2 in 31.8 instead of 35.0 us; from four polynomials on the
+        // 16-element kernels win again (same-box A/B: profiles/r03_ntt_small_workitems_probe.jsonl)
+        if (log_n == 20 && !rev && batch == 1) { lc[0] = lc[1] = 2; le[0] = le[1] = 2; }
+        if (log_n == 20 && !rev && batch == 2) { lc[0] = lc[1] = 3; le[0] = le[1] = 3; }
         if (log_n == 22 && big) { np = 2; lr[0] = 10; lr[1] = 12; lc[0] = 4; lc[1] = 3; le[0] = 5; le[1] = 6; }
         if (log_n == 24 && big) { np = 3; lr[0] = 10; lr[1] = lr[2] = 7; lc[0] = 4; lc[1] = lc[2] = 5; le[0] = 5; le[1] = le[2] = 4; }
     }
@@ -117,8 +123,8 @@ static inline int glp_make_plan(int log_n, int rev, int in_place, const char* ov
         int last = (i == np - 1);
         ps->mode = last ? ((rev || np == 1) ? GLP_FINAL_ROWS : GLP_FINAL_T) : GLP_STRIP;
         ps->log_m = last ? 0 : rem;
-        int e = le[i] >= 4 ? le[i] : glp_default_log_e(lr[i]);
-        if (e != 4 && !(e == 5 && glp_has_e5(lr[i])) && !(e == 6 && glp_has_e6(lr[i]) && !rev)) return -1;
+        int e = le[i] >= 2 ? le[i] : glp_default_log_e(lr[i]);
+        if (e != 4 && !((e == 3 || e == 2) && lr[i] == 10) && !(e == 5 && glp_has_e5(lr[i])) && !(e == 6 && glp_has_e6(lr[i]) && !rev)) return -1;
         ps->log_e = e;
         const int tmin = 6 + e;                              // 64 .. 1024 threads; radix-32 FINAL_T tiles: <= 256 (GlpBounds, ntt_kernels.cuh)
         const int tmax = e == 6 ? 9 + e : ((e == 5 && ps->mode == GLP_FINAL_T) ? 8 + e : 10 + e);

@@ -70,6 +70,10 @@ struct EmuBackend {
                 } else failed = true;
             } else if (ps.log_e == 5) {
                 if constexpr (LR >= 9) both(glp_ic<5>{});
+            } else if (ps.log_e == 3) {
+                if constexpr (LR == 10) both(glp_ic<3>{}); else failed = true;
+            } else if (ps.log_e == 2) {
+                if constexpr (LR == 10) both(glp_ic<2>{}); else failed = true;
             } else {
                 both(glp_ic<4>{});
             }

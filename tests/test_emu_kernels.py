@@ -53,6 +53,10 @@ CASES = [
     # round 3: radix-64 work-items (2^11 = 32 * 64, 2^12 = 64 * 64: two register steps, one split exchange) — strip and finalT, both tile widths,
     # forward and inverse, in place and out of place, more than one polynomial (the two-pass plans of 2^22 / 2^23 themselves ran here once, bit-exact, and on
     # the GPU against the default plans: profiles/r03_ntt_e6_probe.jsonl)
+    # 8- and 4-element work-items on the 2^10 tile (register steps 2 * 8 * 8 * 8 and 4^5: the defaults of 2^20 x 2 and 2^20 x 1): strip, finalT,
+    # rows / bit-reversed, inverse (the 2^20 defaults themselves: bit-exact here once, 50-60 s each under emulation, and in tests/test_gpu_ntt.py)
+    (16, 2, 0, 0, "10:2:3,6:4", True), (16, 1, 1, 0, "6:4,10:3:3", False), (10, 3, 1, 1, "10:1:3", True),
+    (16, 2, 1, 0, "10:2:2,6:4", False), (16, 1, 0, 0, "6:4,10:2:2", True), (10, 2, 0, 1, "10:1:2", True),
     (17, 2, 0, 0, "11:2:6,6:3", True), (17, 1, 1, 0, "6:3,11:3:6", False), (18, 1, 0, 0, "12:2:6,6:4", True), (18, 3, 1, 0, "6:4,12:3:6", True),
 ]
 

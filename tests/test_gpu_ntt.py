@@ -65,7 +65,38 @@ def test_every_size_vs_oracle(prover, oracle, pkg, log_n):
 
 PLANS = [(16, "8:4,8:4"), (16, "10:2,6:4"), (16, "6:6,10:4"), (18, "6:4,6:4,6:4"), (18, "9:3,9:3"), (20, "10:4,10:4"),
          (20, "10:3,10:3"), (20, "7:5,7:5,6:6"), (20, "12:2,8:4"), (20, "8:4,12:2"), (22, "11:3,11:3"), (22, "8:4,7:5,7:5"),
-         (22, "12:2,10:4")]
+         (22, "12:2,10:4"),
+         # round 3: radix-64 work-items (2^11 / 2^12 tiles in two register steps; natural order only, see test_radix64_plans below) and the small
+         # work-items of latency-bound single transforms (4 and 8 elements per work-item on the 2^10 tile: the defaults of 2^20 x 1 and x 2)
+         (20, "10:2:2,10:2:2"), (20, "10:3:3,10:3:3"), (20, "10:2:2,10:2:3"), (16, "10:2:3,6:4"), (16, "6:4,10:2:2")]
+
+
+@pytest.mark.parametrize("log_n,batch,plan", [(22, 2, "11:3:6,11:3:6"), (22, 1, "10:4:5,12:3:6"), (24, 1, "12:2:6,12:3:6"), (23, 1, "12:3:6,11:2:6"),
+                                              (20, 2, None), (20, 1, None)])
+def test_radix64_plans_and_small_batch_defaults(prover, oracle, pkg, log_n, batch, plan):
+    """natural-order forward and inverse transforms on the radix-64 work-item plans (plain instantiations only: a bit-reversed transform asked
+    of such a plan is refused, not served wrongly) and on the defaults of one and two 2^20 transforms (4- / 8-element work-items), word for word"""
+    rng = np.random.default_rng(log_n * 17 + batch)
+    x = rand_field(rng, (batch, 1 << log_n))
+    x[0, :5] = P - 1
+    if plan is None:
+        assert ("E=4" if batch == 1 else "E=8") in prover.describe_plan(log_n, batch)
+    else:
+        prover.set_plan(log_n, plan)
+    try:
+        for inv in (0, 1):
+            d = prover.to_device(x)
+            prover.ntt_ex(d, d, log_n, batch, flags=inv * pkg.NTT_INVERSE)
+            got = d.download(x.shape)
+            d.free()
+            assert np.array_equal(got, oracle_ntt(oracle, x, inv, 0)), (plan, inv)
+        if plan is not None:
+            d = prover.to_device(x)
+            with pytest.raises(Exception):
+                prover.ntt_ex(d, d, log_n, batch, flags=pkg.NTT_BITREV)
+            d.free()
+    finally:
+        prover.set_plan(log_n, None)
 
 
 @pytest.mark.parametrize("log_n,plan", PLANS)
