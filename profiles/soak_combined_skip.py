@@ -55,7 +55,7 @@ while time.time() < t_end and failed is None:
     if time.time() - t_mark > 60:
         t_mark = time.time()
         print(json.dumps({"progress": {k: stats[k] for k in ("cases", "accepted", "rule_fails_refused", "corrupted", "refused")}}), flush=True)
-    *case, seeds = mr.synthetic_case(4, 5, IDX, trusted_height=2_000_000 + rng.randrange(1 << 20), power_groups=3, seed=rng.randrange(1 << 30), real_keys=True)
+    *case, seeds = mr.synthetic_case(4, 5, IDX, trusted_height=2_500_000 + rng.randrange(1 << 20), power_groups=3, seed=rng.randrange(1 << 30), real_keys=True)
     tf, (tk, tp), chain, (vk, vp), _, idx, h0 = case
     signed = [rng.random() < 0.8 for _ in vk]
     case[4] = signed
