@@ -523,6 +523,17 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
         for k in range(lo, hi, B):
             if any(tuple(len(bytes(f)) for f in h) != self.field_lengths for h in headers[k:k + B]):
                 raise ValueError("a leaf takes leaf_headers headers whose field encodings have the recorded lengths")
+        # The leaf circuit BUILDS each header's height field, the prefix of its data-hash field and the hash inside its last_block_id from (first
+        # height, the predecessor's hash as computed in-circuit): those bytes of the caller's headers are not inputs.  Headers that disagree with
+        # what the circuit will hash are refused here — otherwise the proof would silently be about the chain the circuit implies, not the one given
+        # (found by profiles/soak_combined_skip.py: a flipped bit in the first header of a leaf was ignored).
+        from .blobstream import encode_varint
+        for k in range(lo, hi):
+            f = headers[k]
+            if bytes(f[4])[:34] != b"\x0a\x20" + hashes[k]:
+                raise ValueError(f"header {k} does not name its predecessor's hash in its last_block_id")
+            if bytes(f[2]) != b"\x08" + encode_varint(first_height + k) or bytes(f[6])[:2] != b"\x0a\x20":
+                raise ValueError(f"header {k}: the height field is not the encoding of {first_height + k}, or the data-hash field is malformed")
         return self._map_inputs([_chain_leaf_inputs(hashes[k], first_height + k, headers[k:k + B], self.n_groups) for k in range(lo, hi, B)])
 
     def prove_chain_distributed(self, start_hash, first_height, headers, device=None, comm=None):

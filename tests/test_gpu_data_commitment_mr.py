@@ -200,6 +200,20 @@ def test_header_chain_data_commitment_by_mapreduce(prover, oracle, pkg):
     with pytest.raises(ValueError):
         md.prove_chain(start, first, headers[:2])                               # one leaf: no node to hash its tuples
     md.free()
+    # the bytes of a header that the circuit BUILDS (the hash inside last_block_id, the height field) are not inputs: headers that disagree with
+    # them are refused on the host, at a leaf's first header (k = 2) as inside a leaf (k = 3) — found by profiles/soak_combined_skip.py: the
+    # former used to be ignored and the implied chain proved instead
+    for k in (2, 3, 0):
+        bad = [list(h) for h in headers]
+        f4 = bytearray(bad[k][4])
+        f4[9] ^= 4
+        bad[k][4] = bytes(f4)
+        with pytest.raises(ValueError):
+            mr.prove_chain(start, first, bad)
+    bad = [list(h) for h in headers]
+    bad[4][2] = b"\x08" + bs.encode_varint(first + 5)
+    with pytest.raises(ValueError):
+        mr.prove_chain(start, first, bad)
     # another chain through the recorded programs
     rec_before = dict(mr.record_seconds)
     s2 = hashlib.sha256(b"another").digest()
