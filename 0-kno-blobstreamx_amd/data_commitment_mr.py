@@ -470,6 +470,10 @@ class HeaderChainMapReduce(DataCommitmentMapReduce):
         self.record_seconds["leaf"] = round(time.perf_counter() - t0, 3)
 
     def prove_leaf(self, start_hash, first_height, headers, which=0):
+        """(proof, public) for ONE leaf: the statement is about the chain that starts at start_hash / first_height and carries these headers' OTHER
+        bytes — the hash inside each last_block_id, the height fields and the data-hash prefixes are built in-circuit, the caller's copies of them are
+        not read here (prove_chain / _map_chain compare them with what the circuit builds and refuse a mismatch; a leaf proved at the wrong place
+        does not connect in the nodes)"""
         if self.leaf_program is None:
             self._record_leaf()
         if len(headers) != self.leaf_blocks or any(tuple(len(bytes(f)) for f in h) != self.field_lengths for h in headers):
