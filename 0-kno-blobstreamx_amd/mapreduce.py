@@ -300,9 +300,13 @@ class RecursionFolders:
     that cost); every later fold is witness evaluation + proving.  After fold_local / fold_root, `public` holds the public inputs of the
     proof just made and `key` the verifying key it belongs to."""
 
-    def __init__(self, prover, leaf, poseidon_consts, node_queries=28, node_pow_bits=16):
+    def __init__(self, prover, leaf, poseidon_consts, node_queries=28, node_pow_bits=16, compact=False):
+        """compact: every node states ONLY the Poseidon Merkle root of the LEAF digests below it (4 public words at every level: the root proof's
+        statement does not grow with the number of leaves) instead of its children's public inputs, their digests and the root.  A leaf's digest
+        binds its header, public inputs and caps, so the 4 words are checked against the leaf proofs' digests alone (recursion.merkle_root_host);
+        a level-2 node combines its children's 4-word roots — the tree over all leaves, when every rank folds the same power-of-two count."""
         self.prover, self.leaf, self.consts = prover, dict(leaf), poseidon_consts
-        self.nq, self.pw = node_queries, node_pow_bits
+        self.nq, self.pw, self.compact = node_queries, node_pow_bits, bool(compact)
         self.programs, self.record_seconds = {}, {}
         self.public = self.key = None
         self.local_key = self.local_public_len = None
@@ -322,7 +326,8 @@ class RecursionFolders:
         lf = self.leaf
         rp = self._program(1, proofs, leaf_key=lf["key"], num_queries=lf["num_queries"], pow_bits=lf["pow_bits"], n_wires=lf["n_wires"],
                            n_routed=lf.get("n_routed"), n_public=lf.get("n_public", 0), cap_height=lf.get("cap_height", 4),
-                           child_is_recursion=bool(lf.get("poseidon", False)), child_sha=bool(lf.get("sha", False)))
+                           child_is_recursion=bool(lf.get("poseidon", False)), child_sha=bool(lf.get("sha", False)),
+                           combine=(lambda b, outs: _root_of(b, [o["digest"] for o in outs])) if self.compact else None)
         proof, self.public = rp.prove(proofs, self.nq, self.pw)
         self.key = self.local_key = rp.key()
         self.local_public_len = len(self.public)
@@ -332,7 +337,8 @@ class RecursionFolders:
         if self.local_key is None:
             raise RuntimeError("fold_root before fold_local: the level-1 circuit (its key, its public-input count) is not known yet")
         rp = self._program(2, node_proofs, leaf_key=self.local_key, num_queries=self.nq, pow_bits=self.pw, n_wires=rp_wires(self.programs),
-                           n_routed=80, n_public=self.local_public_len, cap_height=1, child_is_recursion=True)
+                           n_routed=80, n_public=self.local_public_len, cap_height=1, child_is_recursion=True,
+                           combine=(lambda b, outs: _root_of(b, [o["public"] for o in outs])) if self.compact else None)
         proof, self.public = rp.prove(node_proofs, self.nq, self.pw)
         self.key = rp.key()
         return proof
@@ -341,6 +347,15 @@ class RecursionFolders:
         for rp in self.programs.values():
             rp.free()
         self.programs = {}
+
+
+def _root_of(b, digests):
+    """Poseidon Merkle root (two_to_one levels) of a power-of-two list of 4-variable digests, on builder b"""
+    level = [list(d) for d in digests]
+    assert all(len(d) == 4 for d in level) and len(level) & (len(level) - 1) == 0
+    while len(level) > 1:
+        level = [b.two_to_one(level[2 * k], level[2 * k + 1]) for k in range(len(level) // 2)]
+    return level[0]
 
 
 def rp_wires(programs):
