@@ -3,7 +3,7 @@
 (skip = 8, 2-header leaves, 4 trusted / 5 target validators of which 3 are shared; 6 queries / 4 PoW bits): per iteration a fresh random case —
 keys, powers, headers, which validators signed — proved through the header-chain MapReduce, the signature-set MapReduce and the outer circuit.
 When the signers hold > 2/3 of the target power and the shared signers > 1/3 of the trusted power the root must verify for exactly the statement
-recomputed on the host (hashlib, host signer digest); otherwise the case must be REFUSED.  Every second provable case is then corrupted in one random
+recomputed on the host (hashlib, host signer digest) under the key a SECOND object on other ctxs derived for itself; otherwise the case must be REFUSED.  Every second provable case is then corrupted in one random
 way — a broken chain link, a header at another height, a target header naming another validator set, a forged signature, a vote for another block —
 and must be refused."""
 import hashlib
@@ -47,6 +47,13 @@ def statement(case):
                 commitment=tm_root([h0 + 1 + k for k in range(SKIP)], [f[6][2:] for f in chain]))
 
 
+# the VERIFIER's key: from a setup of its own on another ctx (never the key a prover hands over)
+vp_ = [pkg.Prover(0) for _ in range(2)]
+for p in vp_:
+    p.set_poseidon_constants(*consts)
+vsigs = sm.SignatureSetMapReduce(vp_[1], consts, msg_len=48, hash_offset=8, fan_in=2, num_queries=6, pow_bits=4)
+vmr = cs.CombinedSkipMapReduce(vp_[0], consts, skip=SKIP, batch=2, fan_in=2, num_queries=6, pow_bits=4, max_skip=100, signatures=vsigs)
+VKEY = vmr.expected_key(4, 5, IDX, power_groups=3)
 rng = random.Random(777)
 stats = {"cases": 0, "provable": 0, "accepted": 0, "rule_fails": 0, "rule_fails_refused": 0, "corrupted": 0, "refused": 0, "by_kind": {}}
 t_end, t_mark = time.time() + budget, time.time()
@@ -73,8 +80,8 @@ while time.time() < t_end and failed is None:
     stats["provable"] += 1
     out = mr.prove_skip(*case, votes=votes)
     want = statement(tuple(case))
-    ok = all(out[k] == want[k] for k in want) and mr.verify(out["root_proof"], out["key"], **want)
-    ok = ok and not mr.verify(out["root_proof"], out["key"], **dict(want, target_block=want["target_block"] + 1))
+    ok = all(out[k] == want[k] for k in want) and np.array_equal(out["key"], VKEY) and vmr.verify(out["root_proof"], VKEY, **want)
+    ok = ok and not vmr.verify(out["root_proof"], VKEY, **dict(want, target_block=want["target_block"] + 1))
     stats["accepted"] += bool(ok)
     if not ok:
         failed = {"FAILED": "accept", "signed": signed}
@@ -113,7 +120,7 @@ if failed:
 stats["seconds"] = round(budget, 1)
 stats["all_ok"] = failed is None and stats["accepted"] == stats["provable"] and stats["refused"] == stats["corrupted"] and stats["rule_fails_refused"] == stats["rule_fails"]
 print(json.dumps(stats), flush=True)
-mr.free()
-sigs.free()
-for p in provers:
+for o in (mr, sigs, vmr, vsigs):
+    o.free()
+for p in provers + vp_:
     p.close()
