@@ -7,6 +7,9 @@
  *   - Goldilocks product reduced by hand (2^64 = 2^32 - 1, 2^96 = -1), no division;
  *   - iterative radix-2 DIT with a precomputed twiddle table per stage laid out
  *     contiguously (unit-stride twiddle reads), bit-reversal by table;
+ *   - branch-free field operations (round 3: the data-dependent corrections of add / sub / mul were branches — a coin flip per
+ *     butterfly — and most of the run time: 3.2 -> 7.2-7.7 GB/s on the GPU box's 16-thread quota; a four-step, cache-blocked form was
+ *     measured on the same box and is no faster: the loop is arithmetic-bound, not memory-bound);
  *   - OpenMP across the batch (one transform per thread at a time).
  * tests/test_oracle.py checks it bit-for-bit against orc_ntt and the golden vectors.
  * PARITY UNPINNED w.r.t. the reference (no reference source exists in the mount); this is
@@ -20,29 +23,53 @@ typedef unsigned __int128 u128;
 #define P 0xFFFFFFFF00000001ULL
 #define EPS 0xFFFFFFFFULL
 
+/* branch-free: the corrections below depend on the data (a coin flip per butterfly for random inputs); as branches they were most of the time */
 static inline uint64_t f_add(uint64_t a, uint64_t b) {
     uint64_t s = a + b;
-    return (s < a || s >= P) ? s + EPS : s;
+    return s + ((0 - (uint64_t)((s < a) | (s >= P))) & EPS);
 }
 static inline uint64_t f_sub(uint64_t a, uint64_t b) {
-    uint64_t d = a - b;
-    return a < b ? d - EPS : d;
+    return (a - b) - ((0 - (uint64_t)(a < b)) & EPS);
 }
 static inline uint64_t f_mul(uint64_t a, uint64_t b) {
     u128 x = (u128)a * b;
     uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
     uint64_t hh = hi >> 32, hl = hi & EPS;
-    uint64_t t0 = lo - hh;
-    if (lo < hh) t0 -= EPS;
+    uint64_t t0 = (lo - hh) - ((0 - (uint64_t)(lo < hh)) & EPS);
     uint64_t t1 = hl * EPS;
     uint64_t r = t0 + t1;
-    if (r < t1) r += EPS;
-    return r >= P ? r - P : r;
+    r += (0 - (uint64_t)(r < t1)) & EPS;
+    return r - ((0 - (uint64_t)(r >= P)) & P);
 }
 static uint64_t f_pow(uint64_t a, uint64_t e) {
     uint64_t r = 1;
     while (e) { if (e & 1) r = f_mul(r, a); a = f_mul(a, a); e >>= 1; }
     return r;
+}
+
+/* in-place radix-2 DIT of one contiguous 2^log_m-point vector: tw = per-stage twiddles (stage s at tw + 2^(s-1) - 1), rev = bit-reversal table */
+static void fft_small(uint64_t *a, unsigned log_m, const uint64_t *tw, const uint32_t *rev) {
+    const uint64_t m_ = 1ULL << log_m;
+    for (uint64_t i = 0; i < m_; i++) { uint32_t r = rev[i]; if (r > i) { uint64_t t = a[i]; a[i] = a[r]; a[r] = t; } }
+    for (unsigned s = 1; s <= log_m; s++) {
+        const uint64_t half = 1ULL << (s - 1), m = half << 1;
+        const uint64_t *ts = tw + half - 1;
+        for (uint64_t k = 0; k < m_; k += m)
+            for (uint64_t j = 0; j < half; j++) {
+                uint64_t u = a[k + j], v = f_mul(a[k + j + half], ts[j]);
+                a[k + j] = f_add(u, v);
+                a[k + j + half] = f_sub(u, v);
+            }
+    }
+}
+static void fill_tables(unsigned log_m, uint64_t w, uint64_t *tw, uint32_t *rev) {
+    const uint64_t m = 1ULL << log_m;
+    for (unsigned s = 1; s <= log_m; s++) {
+        uint64_t half = 1ULL << (s - 1), ws = f_pow(w, m >> s), t = 1;
+        for (uint64_t j = 0; j < half; j++) { tw[half - 1 + j] = t; t = f_mul(t, ws); }
+    }
+    rev[0] = 0;
+    for (uint64_t i = 1; i < m; i++) rev[i] = (rev[i >> 1] >> 1) | ((uint32_t)(i & 1) << (log_m - 1));
 }
 
 void orc_ntt_fast(uint64_t *data, unsigned log_n, uint64_t batch, int inverse) {
@@ -51,30 +78,15 @@ void orc_ntt_fast(uint64_t *data, unsigned log_n, uint64_t batch, int inverse) {
     extern uint64_t orc_two_adic_generator(void);        /* gl_oracle.c: the tests set it to the product build's generator */
     uint64_t w = f_pow(orc_two_adic_generator(), 1ULL << (32 - log_n));
     if (inverse) w = f_pow(w, P - 2);
+    const uint64_t ninv = f_pow(n % P, P - 2);
     /* per-stage twiddles, stage s (half = 2^(s-1)) stored at tw + half - 1 */
     uint64_t *tw = (uint64_t *)malloc(sizeof(uint64_t) * n);
-    for (unsigned s = 1; s <= log_n; s++) {
-        uint64_t half = 1ULL << (s - 1), ws = f_pow(w, n >> s), t = 1;
-        for (uint64_t j = 0; j < half; j++) { tw[half - 1 + j] = t; t = f_mul(t, ws); }
-    }
     uint32_t *rev = (uint32_t *)malloc(sizeof(uint32_t) * n);
-    rev[0] = 0;
-    for (uint64_t i = 1; i < n; i++) rev[i] = (rev[i >> 1] >> 1) | ((uint32_t)(i & 1) << (log_n - 1));
-    const uint64_t ninv = f_pow(n % P, P - 2);
+    fill_tables(log_n, w, tw, rev);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t b = 0; b < (int64_t)batch; b++) {
         uint64_t *a = data + (uint64_t)b * n;
-        for (uint64_t i = 0; i < n; i++) { uint32_t r = rev[i]; if (r > i) { uint64_t t = a[i]; a[i] = a[r]; a[r] = t; } }
-        for (unsigned s = 1; s <= log_n; s++) {
-            const uint64_t half = 1ULL << (s - 1), m = half << 1;
-            const uint64_t *ts = tw + half - 1;
-            for (uint64_t k = 0; k < n; k += m)
-                for (uint64_t j = 0; j < half; j++) {
-                    uint64_t u = a[k + j], v = f_mul(a[k + j + half], ts[j]);
-                    a[k + j] = f_add(u, v);
-                    a[k + j + half] = f_sub(u, v);
-                }
-        }
+        fft_small(a, log_n, tw, rev);
         if (inverse) for (uint64_t i = 0; i < n; i++) a[i] = f_mul(a[i], ninv);
     }
     free(tw);
